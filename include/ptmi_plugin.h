@@ -1,0 +1,214 @@
+/*
+ * ptmi_plugin.h — C-ABI of libunity-webgpu-pathtracer-plugin.so, the MI355X drop-in.
+ *
+ * Part 1 re-exports, symbol for symbol, the native plugin the Unity C# host binds with
+ *   [DllImport("unity-webgpu-pathtracer-plugin")]  (Assets/Scripts/util/TinyBVH.cs:15-50)
+ * and that the reference builds from Assets/Plugins/Web/plugin.cpp (Plugin/CMakeLists.txt:7-11).
+ *
+ * Part 2 adds the render entry points.  The reference has no render FFI: it renders
+ * through Unity's ComputeShader API (Assets/Scripts/PathTracer.cs:226-252).  The PT*
+ * functions below take exactly what those calls bind: the buffers of
+ * BVHScene.PrepareShader (Assets/Scripts/util/BVHScene.cs:140-167) and the uniforms of
+ * PathTracer.OnRenderImage (PathTracer.cs:230-249), and replace DispatchCompute (:251).
+ *
+ * Conventions: cdecl, blittable arguments only (pointers, ints, floats, POD structs);
+ * inputs are borrowed for the duration of the call; outputs returned by Get*Data are
+ * owned by the library until the matching Destroy*.  Functions that returned C++ `bool`
+ * in the reference return a full-width int 0/1 here (ABI-compatible with both the 1-byte
+ * and the 4-byte marshalling of C# `bool`).  Nothing in this library ever calls exit():
+ * degenerate input yields a negative handle / error code and PTGetLastError() text.
+ * Like the reference (unsynchronised globals, plugin.cpp:5-6) the handle tables are
+ * single-threaded by contract.
+ */
+#ifndef PTMI_PLUGIN_H
+#define PTMI_PLUGIN_H
+
+#include <stdint.h>
+#include "ptmi_layouts.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(_WIN32)
+#define PT_API __declspec(dllexport)
+#else
+#define PT_API __attribute__((visibility("default")))
+#endif
+
+/* ------------------------------------------------------------------------------------
+ * Part 1 — acceleration-structure exports (replaces Assets/Plugins/Web/plugin.h:14-29)
+ * ------------------------------------------------------------------------------------ */
+
+/* plugin.cpp:35-40.  Synchronous CWBVH build over 3*triangleCount 16-byte vertices
+ * (w ignored).  Returns the handle (first free slot), or -1 on triangleCount <= 0 / NULL. */
+PT_API int   BuildBVH(const PTFloat4* vertices, int triangleCount);
+/* plugin.cpp:42-52.  Out-of-range or already-destroyed handle is a no-op. */
+PT_API void  DestroyBVH(int index);
+/* plugin.cpp:54-58 */
+PT_API int   IsBVHReady(int index);
+/* plugin.cpp:23-33.  Opaque object pointer (never dereferenced by the C# host). */
+PT_API void* GetBVHPtr(int index);
+PT_API void* GetBVH(int index);
+/* plugin.cpp:60-64.  BYTES of CWBVH node data (nodes * 80); 0 for an invalid handle. */
+PT_API int   GetCWBVHNodesSize(int index);
+/* plugin.cpp:66-70.  BYTES of CWBVH triangle data (triangles * 48). */
+PT_API int   GetCWBVHTrisSize(int index);
+/* plugin.cpp:72-86.  Borrowed pointers, valid until DestroyBVH(index). */
+PT_API int   GetCWBVHData(int index, PTFloat4** bvhNodes, PTFloat4** bvhTris);
+
+/* plugin.cpp:111-118.  2-wide SAH BVH over the instances' world AABBs, Aila-Laine layout. */
+PT_API int   BuildTLAS(const PTBlasInstance* instances, int instanceCount);
+PT_API void  DestroyTLAS(int index);                                     /* plugin.cpp:120-130 */
+PT_API int   IsTLASReady(int index);                                     /* plugin.cpp:132-136 */
+PT_API int   GetTLASNodesSize(int index);                                /* plugin.cpp:138-142, bytes = nodes*64 */
+PT_API int   GetTLASData(int index, PTFloat4** tlasNodes, uint32_t** tlasIndices); /* plugin.cpp:144-158 */
+
+/* ------------------------------------------------------------------------------------
+ * Part 2 — render entry points (replace the ComputeShader dispatch of PathTracer.cs:226-252)
+ * ------------------------------------------------------------------------------------ */
+
+typedef struct PTContext PTContext;   /* opaque; one per GPU (one process per GPU) */
+
+/* Feature bits = the reference's shader keywords (PathTracer.compute:6-9). */
+#define PT_FEATURE_HAS_LIGHTS    0x1u   /* HAS_LIGHTS   (PathTracer.cs:372,469) */
+#define PT_FEATURE_HAS_TEXTURES  0x2u   /* HAS_TEXTURES (PathTracer.cs:185)     */
+#define PT_FEATURE_HAS_TLAS      0x4u   /* HAS_TLAS     (BVHScene.cs:145-149); not implemented yet -> PT_ERR_UNSUPPORTED */
+
+/* The buffers BVHScene.PrepareShader binds (BVHScene.cs:151-166) + Lights (PathTracer.cs:471).
+ * All pointers are HOST pointers; PTSetScene copies them into HBM. */
+typedef struct PTSceneDesc {
+    const void*     bvhNodes;        uint64_t bvhNodesBytes;     /* PTCwbvhNode[]          "BVHNodes" */
+    const void*     bvhTris;         uint64_t bvhTrisBytes;      /* PTCwbvhTri[]           "BVHTris"  */
+    const void*     triAttrs;        uint64_t triAttrsBytes;     /* PTTriangleAttributes[] "TriangleAttributesBuffer" */
+    const void*     materials;       uint32_t materialCount;  uint32_t _pad0;  /* PTMaterialData[] "Materials" */
+    const void*     lights;          uint32_t lightCount;     uint32_t _pad1;  /* PTLight[] "Lights" + LightCount */
+    const uint32_t* textureData;     uint64_t textureDataUints;  /* "TextureData": K x {w,h,offset,0} then texels */
+    uint32_t        features;        uint32_t _pad2;             /* PT_FEATURE_* */
+} PTSceneDesc;
+
+/* The uniform block PathTracer.OnRenderImage sets every frame (PathTracer.cs:230-249;
+ * declarations util/globals.hlsl:7-17, util/camera.hlsl:7-10, PathTracer.compute:40-41).
+ * Matrices are 16 floats in Unity Matrix4x4 memory order: element (row r, col c) at [c*4+r],
+ * applied to column vectors (mul(M, v)). */
+typedef struct PTFrameParams {
+    float    CamInvProj[16];          /* _camera.projectionMatrix.inverse  (PathTracer.cs:230) */
+    float    CamToWorld[16];          /* _camera.cameraToWorldMatrix       (PathTracer.cs:231) */
+    uint32_t RngSeedRoot;             /* fresh random value per frame      (PathTracer.cs:233) */
+    uint32_t MaxRayBounces;           /* host passes max(.,1)              (PathTracer.cs:234) */
+    int32_t  SamplesPerPass;          /* host passes max(1,.)              (PathTracer.cs:235) */
+    uint32_t OutputWidth;
+    uint32_t OutputHeight;
+    uint32_t CurrentSample;           /* samples already accumulated       (PathTracer.cs:238) */
+    int32_t  EnvironmentMode;         /* 0 environment colour, 1 basic sky (PathTracer.cs:239) */
+    float    EnvironmentIntensity;
+    float    EnvironmentColor[4];
+    float    EnvironmentMapRotation;  /* only read by HAS_ENVIRONMENT_TEXTURE (not built)      */
+    float    FocalLength;
+    float    Aperture;
+    int32_t  UseFireflyFilter;
+    float    MaxFireflyLuminance;
+    int32_t  UseRussianRoulette;
+    /* DispatchCompute(kernel, dispatchX, dispatchY, 1) group counts of 8x8 threads
+     * (PathTracer.cs:203-208,251).  0,0 = cover every pixel (ceil).  The C# host uses integer
+     * division there, so for sizes that are not multiples of 8 it leaves edge pixels untouched;
+     * pass its values to reproduce that exactly. */
+    uint32_t DispatchGroupsX;
+    uint32_t DispatchGroupsY;
+} PTFrameParams;
+
+/* Work counters, accumulated over passes since the last PTResetStats.  One "ray" is one
+ * call of RayIntersectBvh (util/bvh.hlsl:126): SURVEY.md §8(d). */
+typedef struct PTStats {
+    uint64_t paths;                /* samples started (pixels * SamplesPerPass)            */
+    uint64_t closestHitRays;       /* RayIntersect calls      (util/bvh.hlsl:217)          */
+    uint64_t shadowRays;           /* ShadowRayIntersect calls (util/bvh.hlsl:228)         */
+    uint64_t nodeVisits;           /* CWBVH nodes fetched + tested (80 B each)             */
+    uint64_t triTests;             /* IntersectTriangle calls (48 B each)                  */
+    uint64_t attrFetches;          /* TriangleAttributes fetched (128 B each)              */
+    uint64_t materialFetches;      /* MaterialData fetched (128 B each)                    */
+    uint64_t lightFetches;         /* Light records read (64 B each)                       */
+    uint64_t texelFetches;         /* texels read (4 B each)                               */
+    uint64_t texDescriptorFetches; /* texture descriptors read (16 B each)                 */
+    uint64_t pixelsWritten;        /* Output texels written (16 B each)                    */
+    uint64_t pixelsRead;           /* AccumulatedOutput texels read (16 B each)            */
+    uint64_t maxStackDepth;        /* deepest traversal stack seen (reference limit is 32) */
+    uint64_t stackOverflows;       /* rays that would have exceeded BVH_STACK_SIZE         */
+} PTStats;
+
+/* Device-side timing of the render kernels, measured with HIP events recorded on the
+ * context's own stream around each launch (enabled by PTSetProfiling). */
+typedef struct PTTimings {
+    uint64_t passes;               /* passes timed since the last reset          */
+    double   kernelMsTotal;        /* sum of event-to-event kernel time, ms      */
+    double   kernelMsLast;         /* the most recent pass                        */
+    uint64_t kernelLaunches;       /* device kernels launched in those passes     */
+} PTTimings;
+
+/* Error codes (negative int returns). */
+#define PT_OK                 0
+#define PT_ERR_INVALID_ARG   -1
+#define PT_ERR_NO_DEVICE     -2   /* HIP runtime / MI355X not available: the product path never falls back to a CPU */
+#define PT_ERR_HIP           -3
+#define PT_ERR_NO_SCENE      -4
+#define PT_ERR_UNSUPPORTED   -5
+
+/* Create a render context on HIP device `deviceIndex`.  Fails with PT_ERR_NO_DEVICE when
+ * there is no GPU: there is no CPU fallback. */
+PT_API int PTCreate(int deviceIndex, PTContext** outCtx);
+PT_API int PTDestroy(PTContext* ctx);
+
+/* Copy the scene buffers into HBM (replaces ComputeBuffer.SetData, BVHScene.cs:640-667). */
+PT_API int PTSetScene(PTContext* ctx, const PTSceneDesc* scene);
+
+/* Screen-tile sharding for one-process-per-GPU rendering (no reference counterpart;
+ * SURVEY.md §8e).  The frame is cut into 16x16-pixel blocks; block (bx,by) belongs to rank
+ * (bx + by) % worldSize.  A context renders only its own blocks and writes exact zeros
+ * (rgba = 0) elsewhere, so that a sum over ranks reproduces the single-GPU frame bit for bit.
+ * rank 0 / worldSize 1 (the default) owns everything. */
+PT_API int PTSetTileOwnership(PTContext* ctx, int rank, int worldSize);
+
+/* One progressive pass = one DispatchCompute of the PathTracer kernel (PathTracer.cs:251),
+ * using the context's internal ping-pong frames exactly as PathTracer.cs:246-247,268-272:
+ * Output = frame[cur], AccumulatedOutput = frame[1-cur]; the caller advances CurrentSample
+ * and calls PTFlipFrames()/PTResetFrames() as the C# host flips _currentRT / calls Reset(). */
+PT_API int PTRenderPass(PTContext* ctx, const PTFrameParams* params);
+PT_API int PTFlipFrames(PTContext* ctx);       /* _currentRT = 1 - _currentRT  (PathTracer.cs:271-272) */
+PT_API int PTResetFrames(PTContext* ctx);      /* Reset(): _currentRT = 0      (PathTracer.cs:318-322) */
+
+/* Same pass, but into caller-owned DEVICE buffers (float4 per pixel, row-major):
+ * dOutput is written, dAccumulated (may be NULL when CurrentSample == 0) is read. */
+PT_API int PTRenderPassTo(PTContext* ctx, const PTFrameParams* params, void* dOutput, const void* dAccumulated);
+
+/* Block until every pass launched so far has finished. */
+PT_API int PTSynchronize(PTContext* ctx);
+/* Copy the current Output frame (frame[cur]) to host memory: width*height float4. */
+PT_API int PTReadback(PTContext* ctx, float* dstRGBA, uint64_t dstFloats);
+/* Device pointer of internal frame `which` (0/1) or of the current Output frame (-1). */
+PT_API void* PTGetFramePointer(PTContext* ctx, int which);
+/* The hipStream_t (as void*) all passes of this context are launched on. */
+PT_API void* PTGetStream(PTContext* ctx);
+
+/* Counters: level 0 = rays/paths only (always on, free), 1 = full PTStats (slower kernel variant). */
+PT_API int PTSetStatsLevel(PTContext* ctx, int level);
+PT_API int PTGetStats(PTContext* ctx, PTStats* out);
+PT_API int PTResetStats(PTContext* ctx);
+
+PT_API int PTSetProfiling(PTContext* ctx, int enabled);
+PT_API int PTGetTimings(PTContext* ctx, PTTimings* out);
+PT_API int PTResetTimings(PTContext* ctx);
+
+/* Select the kernel schedule: 0 = default, others are named in DESIGN.md.  All schedules
+ * produce bit-identical frames. */
+PT_API int PTSetSchedule(PTContext* ctx, int schedule);
+
+/* Text of the last error on the calling thread ("" if none). */
+PT_API const char* PTGetLastError(void);
+/* Library/ABI version: (major << 16) | minor. */
+PT_API int PTGetVersion(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* PTMI_PLUGIN_H */

@@ -1,0 +1,71 @@
+/*
+ * oracle/pt_oracle.h — C interface of the CPU oracle (TEST INFRASTRUCTURE ONLY).
+ *
+ * The oracle is a scalar CPU restatement of the reference's compute-shader path
+ * (Assets/Resources/PathTracer.compute + Assets/Resources/util/ *.hlsl).  It is the checker the
+ * MI355X kernels are compared against; it is never shipped, never linked into the product
+ * library, and only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ *
+ * Parity pinning: the reference has NO tests, golden vectors or fixtures of its
+ * own, and its HLSL cannot be executed in the build container (no dxc/tint/Unity).  The oracle is
+ * therefore pinned by (1) byte-exact CWBVH/TLAS data from the reference plugin compiled in place
+ * (oracle/_ref), (2) cross-checks of the restated CWBVH traversal against the reference's own
+ * tinybvh CPU walkers BVH::Intersect / IsOccluded (oracle/ref_driver.cpp), (3) the RNG known-answer
+ * vectors of SURVEY.md Appendix D, (4) analytic checks (white furnace, Lambert under one rectangle
+ * light, lobe pdfs integrate to 1).  The SHADING half (brdf/light/material .hlsl) has no executable
+ * reference here: for it, parity is "unpinned" beyond (3) and (4) and says so in DESIGN.md.
+ */
+#ifndef PT_ORACLE_H
+#define PT_ORACLE_H
+
+#include <stdint.h>
+#include "ptmi_plugin.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* One traced ray as the oracle saw it (for the CPU-baseline ray list). */
+typedef struct OracleRay {
+    float origin[3];
+    float direction[3];
+    float tmax;
+    float kind;        /* 0 = closest hit (RayIntersect), 1 = shadow (ShadowRayIntersect) */
+} OracleRay;
+
+typedef struct OracleOptions {
+    int32_t  x0, y0, x1, y1;      /* pixel window [x0,x1) x [y0,y1); all zero = whole frame        */
+    int32_t  threads;             /* worker threads (rows are interleaved); <= 0 -> 1               */
+    int32_t  shadowAnyHit;        /* 0 = reference-faithful full traversal for shadow rays,
+                                     1 = stop at the first accepted triangle (same boolean; changes
+                                     only nodeVisits / triTests, used to check the GPU's counters)  */
+    int32_t  tileRank, tileWorld; /* PTSetTileOwnership emulation: non-owned pixels are written 0   */
+    OracleRay* rayDump;           /* optional: receives up to rayDumpCapacity rays (single thread!) */
+    uint64_t rayDumpCapacity;
+    uint64_t rayDumpCount;        /* out */
+} OracleOptions;
+
+/* Renders one pass exactly as one DispatchCompute of the reference kernel would
+ * (PathTracer.compute:45-100).  `accumulated` may be NULL when CurrentSample == 0.
+ * `output` = width*height float4; pixels outside the window are left untouched. */
+int oracle_render(const PTSceneDesc* scene, const PTFrameParams* params, const float* accumulated,
+                  float* output, PTStats* stats, OracleOptions* opt);
+
+/* Traces explicit rays through the restated CWBVH traversal (util/bvh.hlsl:126-215).
+ * rays: n x OracleRay.  outT: hit distance (tmax on a miss); outPrim: hit.triIndex (0xFFFFFFFF on a miss);
+ * outSteps: nodes visited.  Shadow rays (kind 1) report prim = 1 / t = 0 when occluded. */
+int oracle_trace(const PTSceneDesc* scene, const OracleRay* rays, uint64_t n, float* outT,
+                 uint32_t* outPrim, uint32_t* outSteps);
+
+/* Scalar entry points for unit tests. */
+float    oracle_random_float(uint32_t* state);                       /* util/random.hlsl:12-16 */
+float    oracle_math(int fn, float x, float y);                      /* ptmi_math.h: 0 sin 1 cos 2 log 3 log2 4 exp2 5 pow 6 acos 7 asin 8 sqrt 9 rcp */
+/* Evaluates / samples the Disney BSDF in isolation (util/brdf.hlsl:114-340).
+ * material: 32 floats of MaterialData (no textures); V, N, L world-space; returns f via out[0..2], pdf out[3]. */
+void     oracle_eval_brdf(const float* material, const float* V, const float* N, const float* L, float eta, float* out);
+void     oracle_sample_brdf(const float* material, const float* V, const float* N, float eta, uint32_t* rngState, float* outL, float* outFPdf);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
