@@ -1,0 +1,353 @@
+// pt_api.hip — the PT* render entry points of include/ptmi_plugin.h (Part 2).
+//
+// They replace what the reference does through Unity's ComputeShader API: buffer uploads
+// (BVHScene.cs:640-667 ComputeBuffer.SetData), per-frame uniforms + DispatchCompute
+// (PathTracer.cs:226-252) and the ping-pong frame bookkeeping (PathTracer.cs:246-247, 268-272).
+// There is NO CPU fallback: without a HIP device PTCreate fails with PT_ERR_NO_DEVICE.
+#include "pt_launch.h"
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_lastError;
+
+int fail(int code, const std::string& msg)
+{
+    g_lastError = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail(PT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));            \
+    } while (0)
+
+struct DeviceBuffer {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+};
+
+struct EventPair { hipEvent_t start, stop; uint32_t launches; };
+
+} // namespace
+
+struct PTContext {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DeviceBuffer nodes, tris, attrs, materials, lights, tex;
+    DScene scene = {};
+    bool hasScene = false;
+    float4* frames[2] = {nullptr, nullptr};
+    uint32_t frameW = 0, frameH = 0;
+    int cur = 0;
+    int rank = 0, world = 1;
+    int statsLevel = 0;
+    int schedule = 0;
+    unsigned long long* dStats = nullptr;       // 14 counters, PTStats order
+    bool profiling = false;
+    std::vector<EventPair> pending;             // recorded, not yet read
+    std::vector<EventPair> freeEvents;
+    PTTimings timings = {};
+};
+
+namespace {
+
+int upload(PTContext* c, DeviceBuffer& b, const void* src, size_t bytes)
+{
+    if (b.ptr && b.bytes < bytes) { hipFree(b.ptr); b.ptr = nullptr; b.bytes = 0; }
+    if (bytes == 0) return PT_OK;
+    if (!b.ptr) {
+        HIP_TRY(hipMalloc(&b.ptr, bytes));
+        b.bytes = bytes;
+    }
+    HIP_TRY(hipMemcpyAsync(b.ptr, src, bytes, hipMemcpyHostToDevice, c->stream));
+    return PT_OK;
+}
+
+int ensure_frames(PTContext* c, uint32_t w, uint32_t h)
+{
+    if (c->frames[0] && c->frameW == w && c->frameH == h) return PT_OK;
+    for (int i = 0; i < 2; i++) if (c->frames[i]) { hipFree(c->frames[i]); c->frames[i] = nullptr; }
+    size_t bytes = (size_t)w * h * sizeof(float4);
+    for (int i = 0; i < 2; i++) {
+        HIP_TRY(hipMalloc((void**)&c->frames[i], bytes));
+        HIP_TRY(hipMemsetAsync(c->frames[i], 0, bytes, c->stream));
+    }
+    c->frameW = w; c->frameH = h;
+    c->cur = 0;                         // PrepareRenderTexture re-created the targets -> Reset() (PathTracer.cs:211-215)
+    return PT_OK;
+}
+
+int drain_events(PTContext* c)
+{
+    for (auto& ep : c->pending) {
+        HIP_TRY(hipEventSynchronize(ep.stop));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, ep.start, ep.stop));
+        c->timings.passes++;
+        c->timings.kernelMsTotal += ms;
+        c->timings.kernelMsLast = ms;
+        c->timings.kernelLaunches += ep.launches;
+        c->freeEvents.push_back(ep);
+    }
+    c->pending.clear();
+    return PT_OK;
+}
+
+int validate_params(const PTFrameParams* p)
+{
+    if (!p) return fail(PT_ERR_INVALID_ARG, "params == NULL");
+    if (p->OutputWidth == 0 || p->OutputHeight == 0) return fail(PT_ERR_INVALID_ARG, "OutputWidth/OutputHeight == 0");
+    if ((uint64_t)p->OutputWidth * p->OutputHeight > 0x7FFFFFFFull / 4) return fail(PT_ERR_INVALID_ARG, "frame too large");
+    return PT_OK;
+}
+
+int render_to(PTContext* c, const PTFrameParams* p, float4* dOut, const float4* dAcc)
+{
+    if (!c) return fail(PT_ERR_INVALID_ARG, "ctx == NULL");
+    int rc = validate_params(p);
+    if (rc) return rc;
+    if (!c->hasScene) return fail(PT_ERR_NO_SCENE, "PTSetScene has not been called");
+    if (!dOut) return fail(PT_ERR_INVALID_ARG, "output buffer == NULL");
+    if (p->CurrentSample > 0 && !dAcc) return fail(PT_ERR_INVALID_ARG, "CurrentSample > 0 needs an accumulated frame");
+    HIP_TRY(hipSetDevice(c->device));
+
+    PTTileMap tm;
+    tm.rank = (uint32_t)c->rank;
+    tm.world = (uint32_t)c->world;
+    uint32_t covW = p->OutputWidth, covH = p->OutputHeight;
+    if (p->DispatchGroupsX && p->DispatchGroupsX * 8u < covW) covW = p->DispatchGroupsX * 8u;
+    if (p->DispatchGroupsY && p->DispatchGroupsY * 8u < covH) covH = p->DispatchGroupsY * 8u;
+    tm.coverW = covW; tm.coverH = covH;
+    tm.blocksX = (covW + 15u) / 16u;
+    tm.blocksY = (covH + 15u) / 16u;
+
+    EventPair ep = {};
+    if (c->profiling) {
+        if (c->pending.size() >= 4096) { rc = drain_events(c); if (rc) return rc; }
+        if (!c->freeEvents.empty()) { ep = c->freeEvents.back(); c->freeEvents.pop_back(); }
+        else { HIP_TRY(hipEventCreate(&ep.start)); HIP_TRY(hipEventCreate(&ep.stop)); }
+    }
+    // pixels this context does not own must read as exact zeros (sum over ranks == single-GPU frame)
+    if (c->world > 1)
+        HIP_TRY(hipMemsetAsync(dOut, 0, (size_t)p->OutputWidth * p->OutputHeight * sizeof(float4), c->stream));
+
+    if (c->profiling) HIP_TRY(hipEventRecord(ep.start, c->stream));
+    uint32_t launches = 0;
+    switch (c->schedule) {
+    case 0:
+    default:
+        HIP_TRY(pt_launch_megakernel(c->scene, *p, dAcc, dOut, tm, c->dStats, c->statsLevel > 0, c->stream));
+        launches = 1;
+        break;
+    }
+    if (c->profiling) {
+        HIP_TRY(hipEventRecord(ep.stop, c->stream));
+        ep.launches = launches;
+        c->pending.push_back(ep);
+    }
+    return PT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+PT_API int PTCreate(int deviceIndex, PTContext** outCtx)
+{
+    if (!outCtx) return fail(PT_ERR_INVALID_ARG, "outCtx == NULL");
+    *outCtx = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(PT_ERR_NO_DEVICE, std::string("no HIP device available (") + (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
+                                          "); this library has no CPU fallback");
+    if (deviceIndex < 0 || deviceIndex >= count) return fail(PT_ERR_INVALID_ARG, "deviceIndex out of range");
+    HIP_TRY(hipSetDevice(deviceIndex));
+    PTContext* c = new PTContext();
+    c->device = deviceIndex;
+    hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (se != hipSuccess) { delete c; return fail(PT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(se)); }
+    se = hipMalloc((void**)&c->dStats, 16 * sizeof(unsigned long long));
+    if (se != hipSuccess) { hipStreamDestroy(c->stream); delete c; return fail(PT_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(se)); }
+    hipMemsetAsync(c->dStats, 0, 16 * sizeof(unsigned long long), c->stream);
+    *outCtx = c;
+    return PT_OK;
+}
+
+PT_API int PTDestroy(PTContext* c)
+{
+    if (!c) return PT_OK;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (auto* b : {&c->nodes, &c->tris, &c->attrs, &c->materials, &c->lights, &c->tex}) if (b->ptr) hipFree(b->ptr);
+    for (int i = 0; i < 2; i++) if (c->frames[i]) hipFree(c->frames[i]);
+    if (c->dStats) hipFree(c->dStats);
+    for (auto& ep : c->pending) { hipEventDestroy(ep.start); hipEventDestroy(ep.stop); }
+    for (auto& ep : c->freeEvents) { hipEventDestroy(ep.start); hipEventDestroy(ep.stop); }
+    hipStreamDestroy(c->stream);
+    delete c;
+    return PT_OK;
+}
+
+PT_API int PTSetScene(PTContext* c, const PTSceneDesc* s)
+{
+    if (!c || !s) return fail(PT_ERR_INVALID_ARG, "ctx/scene == NULL");
+    if (s->features & PT_FEATURE_HAS_TLAS) return fail(PT_ERR_UNSUPPORTED, "HAS_TLAS is not implemented (SURVEY.md 8f N1)");
+    if (!s->bvhNodes || s->bvhNodesBytes < 80 || s->bvhNodesBytes % 80) return fail(PT_ERR_INVALID_ARG, "bvhNodes must be a non-empty multiple of 80 bytes");
+    if (!s->bvhTris || s->bvhTrisBytes % 48) return fail(PT_ERR_INVALID_ARG, "bvhTris must be a multiple of 48 bytes");
+    if (!s->triAttrs || s->triAttrsBytes % 128) return fail(PT_ERR_INVALID_ARG, "triAttrs must be a multiple of 128 bytes");
+    if (!s->materials || s->materialCount == 0) return fail(PT_ERR_INVALID_ARG, "materials missing");
+    if ((s->features & PT_FEATURE_HAS_LIGHTS) && (!s->lights || s->lightCount == 0)) return fail(PT_ERR_INVALID_ARG, "HAS_LIGHTS without lights");
+    if ((s->features & PT_FEATURE_HAS_TEXTURES) && (!s->textureData || s->textureDataUints == 0)) return fail(PT_ERR_INVALID_ARG, "HAS_TEXTURES without texture data");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    if ((rc = upload(c, c->nodes, s->bvhNodes, s->bvhNodesBytes))) return rc;
+    if ((rc = upload(c, c->tris, s->bvhTris, s->bvhTrisBytes))) return rc;
+    if ((rc = upload(c, c->attrs, s->triAttrs, s->triAttrsBytes))) return rc;
+    if ((rc = upload(c, c->materials, s->materials, (size_t)s->materialCount * 128))) return rc;
+    const bool lights = (s->features & PT_FEATURE_HAS_LIGHTS) != 0;
+    const bool textures = (s->features & PT_FEATURE_HAS_TEXTURES) != 0;
+    if (lights && (rc = upload(c, c->lights, s->lights, (size_t)s->lightCount * 64))) return rc;
+    if (textures && (rc = upload(c, c->tex, s->textureData, (size_t)s->textureDataUints * 4))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));      // inputs are borrowed for the duration of the call only
+    c->scene.nodes = (const uint4*)c->nodes.ptr;
+    c->scene.tris = (const float4*)c->tris.ptr;
+    c->scene.attrs = (const float4*)c->attrs.ptr;
+    c->scene.materials = (const float4*)c->materials.ptr;
+    c->scene.lights = lights ? (const float4*)c->lights.ptr : nullptr;
+    c->scene.tex = textures ? (const uint32_t*)c->tex.ptr : nullptr;
+    c->scene.lightCount = lights ? (int32_t)s->lightCount : 0;
+    c->scene.materialCount = s->materialCount;
+    c->scene.hasLights = lights ? 1u : 0u;
+    c->scene.hasTextures = textures ? 1u : 0u;
+    c->hasScene = true;
+    return PT_OK;
+}
+
+PT_API int PTSetTileOwnership(PTContext* c, int rank, int worldSize)
+{
+    if (!c || worldSize < 1 || rank < 0 || rank >= worldSize) return fail(PT_ERR_INVALID_ARG, "bad rank/worldSize");
+    c->rank = rank;
+    c->world = worldSize;
+    return PT_OK;
+}
+
+PT_API int PTRenderPass(PTContext* c, const PTFrameParams* p)
+{
+    if (!c) return fail(PT_ERR_INVALID_ARG, "ctx == NULL");
+    int rc = validate_params(p);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    if ((rc = ensure_frames(c, p->OutputWidth, p->OutputHeight))) return rc;
+    return render_to(c, p, c->frames[c->cur], c->frames[1 - c->cur]);
+}
+
+PT_API int PTFlipFrames(PTContext* c) { if (!c) return fail(PT_ERR_INVALID_ARG, "ctx == NULL"); c->cur = 1 - c->cur; return PT_OK; }
+PT_API int PTResetFrames(PTContext* c) { if (!c) return fail(PT_ERR_INVALID_ARG, "ctx == NULL"); c->cur = 0; return PT_OK; }
+
+PT_API int PTRenderPassTo(PTContext* c, const PTFrameParams* p, void* dOutput, const void* dAccumulated)
+{
+    return render_to(c, p, (float4*)dOutput, (const float4*)dAccumulated);
+}
+
+PT_API int PTSynchronize(PTContext* c)
+{
+    if (!c) return fail(PT_ERR_INVALID_ARG, "ctx == NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+PT_API int PTReadback(PTContext* c, float* dst, uint64_t dstFloats)
+{
+    if (!c || !dst) return fail(PT_ERR_INVALID_ARG, "ctx/dst == NULL");
+    if (!c->frames[0]) return fail(PT_ERR_INVALID_ARG, "no frame rendered yet");
+    uint64_t need = (uint64_t)c->frameW * c->frameH * 4;
+    if (dstFloats < need) return fail(PT_ERR_INVALID_ARG, "destination too small");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(dst, c->frames[c->cur], need * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+PT_API void* PTGetFramePointer(PTContext* c, int which)
+{
+    if (!c) return nullptr;
+    if (which < 0) return c->frames[c->cur];
+    return which < 2 ? c->frames[which] : nullptr;
+}
+
+PT_API void* PTGetStream(PTContext* c) { return c ? (void*)c->stream : nullptr; }
+
+PT_API int PTSetStatsLevel(PTContext* c, int level)
+{
+    if (!c) return fail(PT_ERR_INVALID_ARG, "ctx == NULL");
+    c->statsLevel = level > 0 ? 1 : 0;
+    return PT_OK;
+}
+
+PT_API int PTGetStats(PTContext* c, PTStats* out)
+{
+    if (!c || !out) return fail(PT_ERR_INVALID_ARG, "ctx/out == NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned long long h[16];
+    HIP_TRY(hipMemcpyAsync(h, c->dStats, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    static_assert(sizeof(PTStats) == 14 * 8, "PTStats is 14 counters");
+    memcpy(out, h, sizeof(PTStats));
+    return PT_OK;
+}
+
+PT_API int PTResetStats(PTContext* c)
+{
+    if (!c) return fail(PT_ERR_INVALID_ARG, "ctx == NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(c->dStats, 0, 16 * sizeof(unsigned long long), c->stream));
+    return PT_OK;
+}
+
+PT_API int PTSetProfiling(PTContext* c, int enabled)
+{
+    if (!c) return fail(PT_ERR_INVALID_ARG, "ctx == NULL");
+    c->profiling = enabled != 0;
+    return PT_OK;
+}
+
+PT_API int PTGetTimings(PTContext* c, PTTimings* out)
+{
+    if (!c || !out) return fail(PT_ERR_INVALID_ARG, "ctx/out == NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = drain_events(c);
+    if (rc) return rc;
+    *out = c->timings;
+    return PT_OK;
+}
+
+PT_API int PTResetTimings(PTContext* c)
+{
+    if (!c) return fail(PT_ERR_INVALID_ARG, "ctx == NULL");
+    int rc = drain_events(c);
+    if (rc) return rc;
+    c->timings = PTTimings{};
+    return PT_OK;
+}
+
+PT_API int PTSetSchedule(PTContext* c, int schedule)
+{
+    if (!c) return fail(PT_ERR_INVALID_ARG, "ctx == NULL");
+    if (schedule != 0) return fail(PT_ERR_UNSUPPORTED, "unknown schedule");
+    c->schedule = schedule;
+    return PT_OK;
+}
+
+PT_API const char* PTGetLastError(void) { return g_lastError.c_str(); }
+PT_API int PTGetVersion(void) { return (0 << 16) | 1; }
+
+} // extern "C"

@@ -1,0 +1,924 @@
+// pt_device.h — device-side building blocks of the MI355X path tracer (gfx950, wave64).
+//
+// Everything here is __device__ code used by the render kernels in pt_kernels.hip.  It implements the
+// reference's hot path (Assets/Resources/PathTracer.compute + Assets/Resources/util/ *.hlsl) on the
+// buffer layouts of include/ptmi_layouts.h, with the canonical fp32 arithmetic of include/ptmi_math.h.
+// Citations (file:line) are relative to /root/reference/Assets/Resources.
+//
+// Compile with -ffp-contract=off: products and sums are separate IEEE operations unless written pt_fma.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ptmi_layouts.h"
+#include "ptmi_math.h"
+#include "ptmi_plugin.h"
+
+#define PT_DEV __device__ __forceinline__
+
+// ------------------------------------------------------------------------------------------
+// small vector algebra (explicit operation order; see DESIGN.md "Canonical arithmetic")
+// ------------------------------------------------------------------------------------------
+struct v2 { float x, y; };
+struct v3 { float x, y, z; };
+struct v4 { float x, y, z, w; };
+
+PT_DEV v3 mk3(float a) { return {a, a, a}; }
+PT_DEV v3 mk3(float a, float b, float c) { return {a, b, c}; }
+PT_DEV v3 operator+(v3 a, v3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+PT_DEV v3 operator-(v3 a, v3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+PT_DEV v3 operator-(v3 a) { return {-a.x, -a.y, -a.z}; }
+PT_DEV v3 operator*(v3 a, v3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+PT_DEV v3 operator*(v3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+PT_DEV v3 operator*(float s, v3 a) { return {s * a.x, s * a.y, s * a.z}; }
+PT_DEV v3 operator/(v3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+PT_DEV v3 operator-(float s, v3 a) { return {s - a.x, s - a.y, s - a.z}; }
+PT_DEV v4 operator+(v4 a, v4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+PT_DEV v4 operator-(v4 a, v4 b) { return {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
+PT_DEV v4 operator*(v4 a, v4 b) { return {a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; }
+PT_DEV v4 operator*(float s, v4 a) { return {s * a.x, s * a.y, s * a.z, s * a.w}; }
+
+PT_DEV float dot3(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+PT_DEV v3 cross3(v3 a, v3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+PT_DEV float length3(v3 v) { return pt_sqrt(dot3(v, v)); }
+PT_DEV v3 normalize3(v3 v) { return v * (1.0f / pt_sqrt(dot3(v, v))); }
+PT_DEV v3 lerp3(v3 a, v3 b, float t) { return a + t * (b - a); }
+PT_DEV v4 lerp4(v4 a, v4 b, float t) { return a + t * (b - a); }
+PT_DEV v3 reflect3(v3 i, v3 n) { return i - (2.0f * dot3(n, i)) * n; }
+PT_DEV v3 refract3(v3 i, v3 n, float eta)
+{
+    float d = dot3(n, i);
+    float k = 1.0f - eta * eta * (1.0f - d * d);
+    if (k < 0.0f) return mk3(0.0f);
+    return eta * i - (eta * d + pt_sqrt(k)) * n;
+}
+PT_DEV float luminance3(v3 c) { return dot3(c, mk3(0.299f, 0.587f, 0.114f)); }     // util/common.hlsl:195-198
+
+struct Onb { v3 x, y, z; };
+PT_DEV v3 onb_to_world(const Onb& b, v3 l) { return b.x * l.x + b.y * l.y + b.z * l.z; }         // util/common.hlsl:386-389
+PT_DEV v3 onb_to_local(const Onb& b, v3 w) { return {dot3(b.x, w), dot3(b.y, w), dot3(b.z, w)}; } // :391-394
+
+// util/common.hlsl:346-384, ONB_METHOD 1
+PT_DEV Onb make_onb(v3 z)
+{
+    float lenSq = dot3(z, z);
+    if (lenSq == 0.0f) return {mk3(1, 0, 0), mk3(0, 1, 0), mk3(0, 0, 1)};
+    z = normalize3(z);
+    float k = 1.0f / pt_max(1.0f + z.z, 0.00001f);
+    float a = z.y * k;
+    float b = z.y * a;
+    float c = -z.x * a;
+    v3 x = normalize3(mk3(z.z + b, c, -z.x));
+    v3 y = normalize3(mk3(c, 1.0f - b, -z.y));
+    return {x, y, z};
+}
+
+// ------------------------------------------------------------------------------------------
+// device views of the scene / frame
+// ------------------------------------------------------------------------------------------
+struct DScene {
+    const uint4*  nodes;        // PTCwbvhNode[] as 5 x uint4
+    const float4* tris;         // PTCwbvhTri[] as 3 x float4
+    const float4* attrs;        // PTTriangleAttributes[] as 8 x float4
+    const float4* materials;    // PTMaterialData[] as 8 x float4
+    const float4* lights;       // PTLight[] as 4 x float4
+    const uint32_t* tex;        // TextureData
+    int32_t lightCount;
+    uint32_t materialCount;
+    uint32_t hasLights;
+    uint32_t hasTextures;
+};
+
+struct Counters {
+    uint32_t paths, closestRays, shadowRays, nodeVisits, triTests, attrFetches, materialFetches,
+             lightFetches, texelFetches, texDescFetches, pixelsWritten, pixelsRead, maxStack, overflows;
+};
+
+PT_DEV float rnd(uint32_t& s) { return pt_random_float(&s); }
+
+// ------------------------------------------------------------------------------------------
+// CWBVH traversal.  util/bvh.hlsl:61-215 (Ylitie et al. 2017 as implemented by the reference)
+// ------------------------------------------------------------------------------------------
+// Stack: the reference keeps a private uint2[32] per thread (util/bvh.hlsl:11,131).  Here the first
+// PT_LDS_STACK entries of every lane live in LDS laid out [entry][lane] (one ds_read/write_b64 per
+// lane, bank = 2*lane mod 64: conflict-free whatever depth each lane is at); deeper entries, which the
+// benchmark scenes never reach, spill to a private array.
+#ifndef PT_LDS_STACK
+#define PT_LDS_STACK 12
+#endif
+#define PT_SPILL_STACK (PT_BVH_STACK_SIZE - PT_LDS_STACK)
+
+struct TravStack {
+    uint2* lds;                 // &smem[0][threadIdx.x]; entry stride = blockDim.x
+    uint32_t stride;
+    uint2 spill[PT_SPILL_STACK];
+};
+
+PT_DEV void stack_push(TravStack& st, uint32_t sp, uint2 v)
+{
+    if (sp < PT_LDS_STACK) st.lds[sp * st.stride] = v;
+    else if (sp < PT_BVH_STACK_SIZE) st.spill[sp - PT_LDS_STACK] = v;
+}
+PT_DEV uint2 stack_pop(TravStack& st, uint32_t sp)
+{
+    if (sp < PT_LDS_STACK) return st.lds[sp * st.stride];
+    if (sp < PT_BVH_STACK_SIZE) return st.spill[sp - PT_LDS_STACK];
+    return make_uint2(0u, 0u);
+}
+
+PT_DEV uint32_t byte_of(uint32_t v, int i) { return (v >> (i * 8)) & 0xFFu; }
+
+// util/bvh.hlsl:77-124.  n0..n4 are the five 16-byte rows of the node.
+PT_DEV uint32_t cwbvh_node_hitmask(v3 origin, v3 invDir, uint32_t octinv4, float tmax,
+                                   uint4 n0, uint4 n1, uint4 n2, uint4 n3, uint4 n4)
+{
+    // GetNodeInvDir :61-75
+    uint32_t ex = (byte_of(n0.w, 0) ^ 0x80u) - 0x80u;
+    uint32_t ey = (byte_of(n0.w, 1) ^ 0x80u) - 0x80u;
+    uint32_t ez = (byte_of(n0.w, 2) ^ 0x80u) - 0x80u;
+    float sx = pt_asfloat((ex + 127u) << 23) * invDir.x;
+    float sy = pt_asfloat((ey + 127u) << 23) * invDir.y;
+    float sz = pt_asfloat((ez + 127u) << 23) * invDir.z;
+    float px = (pt_asfloat(n0.x) - origin.x) * invDir.x;
+    float py = (pt_asfloat(n0.y) - origin.y) * invDir.y;
+    float pz = (pt_asfloat(n0.z) - origin.z) * invDir.z;
+    const bool nx = invDir.x < 0.0f, ny = invDir.y < 0.0f, nz = invDir.z < 0.0f;
+    uint32_t hitmask = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        uint32_t meta = i == 0 ? n1.z : n1.w;
+        uint32_t qlox = i == 0 ? n2.x : n2.y, qloy = i == 0 ? n2.z : n2.w, qloz = i == 0 ? n3.x : n3.y;
+        uint32_t qhix = i == 0 ? n3.z : n3.w, qhiy = i == 0 ? n4.x : n4.y, qhiz = i == 0 ? n4.z : n4.w;
+        uint32_t lox = nx ? qhix : qlox, hix = nx ? qlox : qhix;
+        uint32_t loy = ny ? qhiy : qloy, hiy = ny ? qloy : qhiy;
+        uint32_t loz = nz ? qhiz : qloz, hiz = nz ? qloz : qhiz;
+        uint32_t isInner = (meta & (meta << 1)) & 0x10101010u;
+        uint32_t innerMask = (isInner >> 4) * 0xffu;
+        uint32_t bitIndex = (meta ^ (octinv4 & innerMask)) & 0x1F1F1F1Fu;
+        uint32_t childBits = (meta >> 5) & 0x07070707u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float tminx = pt_fma((float)byte_of(lox, j), sx, px);
+            float tmaxx = pt_fma((float)byte_of(hix, j), sx, px);
+            float tminy = pt_fma((float)byte_of(loy, j), sy, py);
+            float tmaxy = pt_fma((float)byte_of(hiy, j), sy, py);
+            float tminz = pt_fma((float)byte_of(loz, j), sz, pz);
+            float tmaxz = pt_fma((float)byte_of(hiz, j), sz, pz);
+            float cmin = pt_max(pt_max(pt_max(tminx, tminy), tminz), 0.0f);
+            float cmax = pt_min(pt_min(pt_min(tmaxx, tmaxy), tmaxz), tmax);
+            if (cmin <= cmax) {
+                uint32_t shiftBits = (childBits >> (j * 8)) & 255u;
+                uint32_t bitShift = (bitIndex >> (j * 8)) & 31u;
+                hitmask |= shiftBits << bitShift;
+            }
+        }
+    }
+    return hitmask;
+}
+
+struct TraceHit {
+    float t;            // hit.distance (PT_FAR_PLANE on a miss)
+    float u, v;         // hit.barycentric
+    uint32_t triIndex;  // hit.triIndex (primitive index from the triangle record)
+};
+
+// util/bvh.hlsl:23-59
+PT_DEV void intersect_triangle(const float4* __restrict__ tris, uint32_t triAddr, v3 o, v3 d, TraceHit& hit)
+{
+    float4 t0 = tris[triAddr + 0], t1 = tris[triAddr + 1], t2 = tris[triAddr + 2];
+    v3 e2 = mk3(t0.x, t0.y, t0.z), e1 = mk3(t1.x, t1.y, t1.z), v0 = mk3(t2.x, t2.y, t2.z);
+    v3 r = cross3(d, e2);
+    float a = dot3(e1, r);
+    if (pt_abs(a) > 0.0000001f) {
+        float f = 1.0f / a;
+        v3 s = o - v0;
+        float u = f * dot3(s, r);
+        if (u >= 0.0f && u <= 1.0f) {
+            v3 q = cross3(s, e1);
+            float v = f * dot3(d, q);
+            if (v >= 0.0f && u + v <= 1.0f) {
+                float dist = f * dot3(e2, q);
+                if (dist > 0.0001f && dist < hit.t) {
+                    hit.u = u; hit.v = v;
+                    hit.triIndex = pt_asuint(t2.w);
+                    hit.t = dist;
+                }
+            }
+        }
+    }
+}
+
+// util/bvh.hlsl:126-199 for one lane.  ANYHIT = shadow ray: stops at the first accepted triangle
+// (ShadowRayIntersect only uses the boolean, util/bvh.hlsl:228-233, so the result is identical).
+template <bool STATS>
+PT_DEV void traverse_cwbvh(const DScene& S, v3 o, v3 d, bool anyHit, TraceHit& hit, TravStack& st, Counters& cn)
+{
+    v3 invDir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    uint32_t octinv4 = (7u - ((d.x < 0.0f ? 4u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 1u : 0u))) * 0x1010101u;
+    uint32_t sp = 0;
+    uint2 ng = make_uint2(0u, 0x80000000u);
+    uint2 tg = make_uint2(0u, 0u);
+    bool overflow = false;
+    while (true) {
+        if (ng.y > 0x00FFFFFFu) {
+            uint32_t mask = ng.y;
+            uint32_t childBitIndex = 31u - (uint32_t)__clz((int)mask);
+            uint32_t childNodeBaseIndex = ng.x;
+            ng.y &= ~(1u << childBitIndex);
+            if (ng.y > 0x00FFFFFFu) {
+                stack_push(st, sp, ng);
+                if (sp >= PT_BVH_STACK_SIZE) overflow = true;
+                sp++;
+                if (STATS) cn.maxStack = sp > cn.maxStack ? sp : cn.maxStack;
+            }
+            uint32_t slotIndex = (childBitIndex - 24u) ^ (octinv4 & 255u);
+            uint32_t relativeIndex = (uint32_t)__popc(mask & ~(0xFFFFFFFFu << slotIndex));
+            uint32_t childNodeIndex = childNodeBaseIndex + relativeIndex;
+            const uint4* np = S.nodes + (size_t)childNodeIndex * 5;
+            uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+            uint32_t hitmask = cwbvh_node_hitmask(o, invDir, octinv4, hit.t, n0, n1, n2, n3, n4);
+            if (STATS) cn.nodeVisits++;
+            ng.x = n1.x;
+            ng.y = (hitmask & 0xFF000000u) | (n0.w >> 24);
+            tg.x = n1.y;
+            tg.y = hitmask & 0x00FFFFFFu;
+        } else {
+            tg = ng;
+            ng = make_uint2(0u, 0u);
+        }
+        while (tg.y != 0u) {
+            uint32_t triangleIndex = 31u - (uint32_t)__clz((int)tg.y);
+            uint32_t triAddr = tg.x + triangleIndex * 3u;
+            intersect_triangle(S.tris, triAddr, o, d, hit);
+            if (STATS) cn.triTests++;
+            tg.y -= 1u << triangleIndex;
+            if (anyHit && hit.t < PT_FAR_PLANE) { tg.y = 0u; ng.y = 0u; sp = 0u; }
+        }
+        if (ng.y <= 0x00FFFFFFu) {
+            if (sp > 0u) { --sp; ng = stack_pop(st, sp); }
+            else break;
+        }
+    }
+    if (STATS && overflow) cn.overflows++;
+}
+
+// ------------------------------------------------------------------------------------------
+// surface hit record (util/common.hlsl:173-193) and hit attribute fetch (util/bvh.hlsl:201-212)
+// ------------------------------------------------------------------------------------------
+struct SurfHit {
+    v3 position;
+    float distance;
+    v3 normal;
+    v3 ffnormal;
+    v2 uv;
+    uint32_t triIndex;
+    int32_t materialIndex;
+    uint32_t isLight;          // intersectType == INTERSECT_LIGHT
+};
+
+PT_DEV v3 interp3(float bu, float bv, v3 a0, v3 a1, v3 a2) { return a0 * (1.0f - bu - bv) + a1 * bu + a2 * bv; }
+
+template <bool STATS>
+PT_DEV void fetch_hit_attributes(const DScene& S, v3 o, v3 d, const TraceHit& th, SurfHit& hit, Counters& cn)
+{
+    const float4* a = S.attrs + (size_t)th.triIndex * 8;
+    float4 n0 = a[0], n1 = a[1], n2 = a[2], uv01 = a[6], uv2m = a[7];
+    if (STATS) cn.attrFetches++;
+    hit.distance = th.t;
+    hit.triIndex = th.triIndex;
+    hit.position = o + th.t * d;
+    hit.normal = normalize3(interp3(th.u, th.v, mk3(n0.x, n0.y, n0.z), mk3(n1.x, n1.y, n1.z), mk3(n2.x, n2.y, n2.z)));
+    hit.ffnormal = dot3(hit.normal, d) <= 0.0f ? hit.normal : -hit.normal;
+    float w = 1.0f - th.u - th.v;
+    hit.uv.x = uv01.x * w + uv01.z * th.u + uv2m.x * th.v;
+    hit.uv.y = uv01.y * w + uv01.w * th.u + uv2m.y * th.v;
+    hit.materialIndex = (int32_t)pt_asuint(uv2m.z);
+    hit.isLight = 0u;
+}
+
+// ------------------------------------------------------------------------------------------
+// analytic lights.  util/intersect.hlsl:6-54
+// ------------------------------------------------------------------------------------------
+struct DLight { v3 position; uint32_t type; v3 emission; float range; v3 u; float area; v3 v; };
+
+PT_DEV DLight load_light(const DScene& S, int i)
+{
+    const float4* p = S.lights + (size_t)i * 4;
+    float4 a = p[0], b = p[1], c = p[2], d = p[3];
+    DLight l;
+    l.position = mk3(a.x, a.y, a.z); l.type = pt_asuint(a.w);
+    l.emission = mk3(b.x, b.y, b.z); l.range = b.w;
+    l.u = mk3(c.x, c.y, c.z); l.area = c.w;
+    l.v = mk3(d.x, d.y, d.z);
+    return l;
+}
+
+template <bool STATS>
+PT_DEV void intersect_lights(const DScene& S, v3 o, v3 d, SurfHit& hit, Counters& cn)
+{
+    if (!S.hasLights) return;
+    for (int i = 0; i < S.lightCount; ++i) {
+        DLight light = load_light(S, i);
+        if (STATS) cn.lightFetches++;
+        if (light.type == PT_LIGHT_TYPE_RECTANGLE) {
+            v3 normal = normalize3(cross3(light.u, light.v));
+            float planeW = dot3(normal, light.position);
+            v3 u = light.u / dot3(light.u, light.u);
+            v3 v = light.v / dot3(light.v, light.v);
+            // RectIntersect :6-27
+            float dt = dot3(d, normal);
+            float t = (planeW - dot3(normal, o)) / dt;
+            float res = PT_FAR_PLANE;
+            if (t > PT_EPSILON) {
+                v3 p = o + d * t;
+                v3 vi = p - light.position;
+                float a1 = dot3(u, vi);
+                if (a1 >= 0.0f && a1 <= 1.0f) {
+                    float a2 = dot3(v, vi);
+                    if (a2 >= 0.0f && a2 <= 1.0f) res = t;
+                }
+            }
+            if (res > 0.0f && res < hit.distance && dot3(normal, d) < 0.0f) {
+                hit.distance = res;
+                hit.position = o + res * d;
+                hit.normal = normal;
+                hit.ffnormal = dot3(hit.normal, d) <= 0.0f ? hit.normal : -hit.normal;
+                hit.triIndex = (uint32_t)i;
+                hit.isLight = 1u;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// textures + material.  util/texture.hlsl:6-76, util/material.hlsl:8-138
+// ------------------------------------------------------------------------------------------
+struct Material {
+    v3 baseColor; float opacity;
+    v3 emission; float alphaMode;
+    float alphaCutoff, anisotropic, metallic, roughness;
+    float subsurface, specularTint, sheen, sheenTint;
+    float clearcoat, clearcoatRoughness, specTrans, ior;
+    float ax, ay, eta, occlusion;
+};
+
+template <bool STATS>
+PT_DEV v4 texture_pixel(const DScene& S, uint32_t off, uint32_t width, uint32_t height, uint32_t x, uint32_t y, Counters& cn)
+{
+    x = x < width - 1u ? x : width - 1u;
+    y = y < height - 1u ? y : height - 1u;
+    uint32_t p = S.tex[off + (y * width + x)];
+    if (STATS) cn.texelFetches++;
+    return {(float)(p & 0xFFu) / 255.0f, (float)((p >> 8) & 0xFFu) / 255.0f,
+            (float)((p >> 16) & 0xFFu) / 255.0f, (float)((p >> 24) & 0xFFu) / 255.0f};
+}
+
+template <bool STATS>
+PT_DEV v4 sample_texture(const DScene& S, int32_t textureIndex, v2 uv, Counters& cn)      // linearSample == true at every call site
+{
+    if (textureIndex < 0) return {0.0f, 0.0f, 0.0f, 0.0f};
+    uint32_t dsc = (uint32_t)textureIndex * 4u;
+    uint32_t width = S.tex[dsc + 0], height = S.tex[dsc + 1], offset = S.tex[dsc + 2];
+    if (STATS) cn.texDescFetches++;
+    float u = uv.x, v = uv.y;
+    while (u > 1.0f) u -= 1.0f;
+    while (v > 1.0f) v -= 1.0f;
+    while (u < 0.0f) u += 1.0f;
+    while (v < 0.0f) v += 1.0f;
+    float tu = u * ((float)width - 1.0f);
+    float tv = v * ((float)height - 1.0f);
+    uint32_t tx = pt_f2u(tu), ty = pt_f2u(tv);
+    v4 p1 = texture_pixel<STATS>(S, offset, width, height, tx, ty, cn);
+    float uF = tu - (float)tx, vF = tv - (float)ty;
+    v4 p2 = texture_pixel<STATS>(S, offset, width, height, tx + 1u, ty, cn);
+    v4 p3 = texture_pixel<STATS>(S, offset, width, height, tx, ty + 1u, cn);
+    v4 p4 = texture_pixel<STATS>(S, offset, width, height, tx + 1u, ty + 1u, cn);
+    return lerp4(lerp4(p1, p2, uF), lerp4(p3, p4, uF), vF);
+}
+
+template <bool STATS>
+PT_DEV Material get_material(const DScene& S, int32_t materialIndex, v3 rayDir, const SurfHit& hit, Counters& cn)
+{
+    const float4* mp = S.materials + (size_t)materialIndex * 8;
+    float4 d1 = mp[0], d2 = mp[1], d3 = mp[2], d4 = mp[3], d5 = mp[4], d6t1 = mp[5], t2 = mp[6], tr = mp[7];
+    if (STATS) cn.materialFetches++;
+    const bool T = S.hasTextures != 0u;
+    v2 uv = hit.uv;
+    v4 bco = {d1.x, d1.y, d1.z, d1.w};
+    if (T && !(d6t1.z < 0.0f)) {                                          // GetBaseColorOpacity :56-69
+        v2 tuv = {uv.x * tr.x + tr.z, uv.y * tr.y + tr.w};
+        v4 px = sample_texture<STATS>(S, pt_f2i(d6t1.z), tuv, cn);
+        bco = px * bco;
+    }
+    Material m;
+    m.baseColor = mk3(bco.x, bco.y, bco.z);
+    m.opacity = bco.w;
+    m.alphaMode = d4.x;
+    m.alphaCutoff = d2.w;
+    m.emission = mk3(d2.x, d2.y, d2.z);
+    if (T && !(t2.y < 0.0f)) {                                            // GetEmission :8-21
+        v4 px = sample_texture<STATS>(S, pt_f2i(t2.y), uv, cn);
+        m.emission = mk3(px.x, px.y, px.z);
+    }
+    float metallic = d3.x, rough = d3.y;
+    if (T && !(d6t1.w < 0.0f)) {                                          // GetMetallicRoughness :40-54
+        v4 px = sample_texture<STATS>(S, pt_f2i(d6t1.w), uv, cn);
+        metallic = px.z;
+        rough = px.y * px.y;
+    }
+    m.metallic = metallic;
+    m.roughness = pt_max(rough, 0.001f);
+    m.subsurface = d5.z;
+    m.specularTint = d4.w;
+    m.sheen = d5.x;
+    m.sheenTint = d5.y;
+    m.clearcoat = d5.w;
+    m.clearcoatRoughness = pt_lerp(0.1f, 0.001f, d6t1.x);
+    m.specTrans = 1.0f - pt_saturate(bco.w);
+    m.ior = pt_clamp(d3.w, 1.001f, 2.0f);
+    m.anisotropic = pt_clamp(d4.y, -0.9f, 0.9f);
+    m.occlusion = 1.0f;
+    if (T && !(t2.z < 0.0f)) {                                            // GetOcclusion :71-82
+        float px = sample_texture<STATS>(S, pt_f2i(t2.z), uv, cn).x;
+        m.occlusion = 1.0f + (px - 1.0f);
+    }
+    float aspect = pt_sqrt(1.0f - m.anisotropic * 0.9f);
+    m.ax = pt_max(0.001f, m.roughness / aspect);
+    m.ay = pt_max(0.001f, m.roughness * aspect);
+    m.eta = (dot3(rayDir, hit.normal) < 0.0f) ? 1.0f / m.ior : m.ior;
+    return m;
+}
+
+// ------------------------------------------------------------------------------------------
+// util/sampling.hlsl
+// ------------------------------------------------------------------------------------------
+PT_DEV float gtr1(float NDotH, float a)
+{
+    if (a >= 1.0f) return PT_INV_PI;
+    float a2 = a * a;
+    float t = 1.0f + (a2 - 1.0f) * NDotH * NDotH;
+    return (a2 - 1.0f) / (PT_PI * pt_log(a2) * t);
+}
+PT_DEV v3 sample_gtr1(float rgh, float r1, float r2)
+{
+    float a = pt_max(0.001f, rgh);
+    float a2 = a * a;
+    float phi = r1 * PT_TWO_PI;
+    float cosTheta = pt_sqrt((1.0f - pt_pow(a2, 1.0f - r2)) / (1.0f - a2));
+    float sinTheta = pt_clamp(pt_sqrt(1.0f - (cosTheta * cosTheta)), 0.0f, 1.0f);
+    float sinPhi = pt_sin(phi);
+    float cosPhi = pt_cos(phi);
+    return mk3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
+}
+PT_DEV v3 sample_ggx_vndf(v3 V, float ax, float ay, float r1, float r2)
+{
+    v3 Vh = normalize3(mk3(ax * V.x, ay * V.y, V.z));
+    float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
+    v3 T1 = lensq > 0.0f ? mk3(-Vh.y, Vh.x, 0.0f) * pt_rsqrt(lensq) : mk3(1, 0, 0);
+    v3 T2 = cross3(Vh, T1);
+    float r = pt_sqrt(r1);
+    float phi = 2.0f * PT_PI * r2;
+    float t1 = r * pt_cos(phi);
+    float t2 = r * pt_sin(phi);
+    float s = 0.5f * (1.0f + Vh.z);
+    t2 = (1.0f - s) * pt_sqrt(1.0f - t1 * t1) + s * t2;
+    v3 Nh = t1 * T1 + t2 * T2 + pt_sqrt(pt_max(0.0f, 1.0f - t1 * t1 - t2 * t2)) * Vh;
+    return normalize3(mk3(ax * Nh.x, ay * Nh.y, pt_max(0.0f, Nh.z)));
+}
+PT_DEV float gtr2_aniso(float NDotH, float HDotX, float HDotY, float ax, float ay)
+{
+    float a = HDotX / ax;
+    float b = HDotY / ay;
+    float c = a * a + b * b + NDotH * NDotH;
+    return 1.0f / (PT_PI * ax * ay * c * c);
+}
+PT_DEV float smith_g(float NDotV, float alphaG)
+{
+    float a = alphaG * alphaG;
+    float b = NDotV * NDotV;
+    return (2.0f * NDotV) / (NDotV + pt_sqrt(a + b - a * b));
+}
+PT_DEV float smith_g_aniso(float NDotV, float VDotX, float VDotY, float ax, float ay)
+{
+    float a = VDotX * ax;
+    float b = VDotY * ay;
+    float c = NDotV;
+    return (2.0f * NDotV) / (NDotV + pt_sqrt(a * a + b * b + c * c));
+}
+PT_DEV float schlick_weight(float u)
+{
+    float m = pt_clamp(1.0f - u, 0.0f, 1.0f);
+    float m2 = m * m;
+    return m2 * m2 * m;
+}
+PT_DEV float dielectric_fresnel(float cosThetaI, float eta)
+{
+    float sinThetaTSq = eta * eta * (1.0f - cosThetaI * cosThetaI);
+    if (sinThetaTSq > 1.0f) return 1.0f;
+    float cosThetaT = pt_sqrt(pt_max(1.0f - sinThetaTSq, 0.0f));
+    float rs = (eta * cosThetaT - cosThetaI) / (eta * cosThetaT + cosThetaI);
+    float rp = (eta * cosThetaI - cosThetaT) / (eta * cosThetaI + cosThetaT);
+    return 0.5f * (rs * rs + rp * rp);
+}
+PT_DEV v3 cosine_sample_hemisphere(float r1, float r2)
+{
+    float r = pt_sqrt(r1);
+    float phi = PT_TWO_PI * r2;
+    v3 d;
+    d.x = r * pt_cos(phi);
+    d.y = r * pt_sin(phi);
+    d.z = pt_sqrt(pt_max(0.0f, 1.0f - d.x * d.x - d.y * d.y));
+    return d;
+}
+PT_DEV float power_heuristic(float a, float b) { float t = a * a; return t / (b * b + t); }
+
+// ------------------------------------------------------------------------------------------
+// util/brdf.hlsl
+// ------------------------------------------------------------------------------------------
+struct Lobes { float dielectricWt, metalWt, glassWt, diffPr, dielectricPr, metalPr, glassPr, clearCtPr; };
+
+PT_DEV void tint_colors(const Material& mat, float eta, float& F0, v3& Csheen, v3& Cspec0)
+{
+    float lum = luminance3(mat.baseColor);
+    v3 ctint = lum > 0.0f ? mat.baseColor / lum : mk3(1.0f);
+    F0 = (1.0f - eta) / (1.0f + eta);
+    F0 *= F0;
+    Cspec0 = F0 * lerp3(mk3(1.0f), ctint, mat.specularTint);
+    Csheen = lerp3(mk3(1.0f), ctint, mat.sheenTint);
+}
+
+PT_DEV Lobes lobe_weights(const Material& mat, v3 Cspec0, float Vz)
+{
+    Lobes w;
+    w.dielectricWt = (1.0f - mat.metallic) * (1.0f - mat.specTrans);
+    w.metalWt = mat.metallic;
+    w.glassWt = (1.0f - mat.metallic) * mat.specTrans;
+    float schlickWt = schlick_weight(Vz);
+    w.diffPr = w.dielectricWt * luminance3(mat.baseColor);
+    w.dielectricPr = w.dielectricWt * luminance3(lerp3(Cspec0, mk3(1.0f), schlickWt));
+    w.metalPr = w.metalWt * luminance3(lerp3(mat.baseColor, mk3(1.0f), schlickWt));
+    w.glassPr = w.glassWt;
+    w.clearCtPr = 0.25f * mat.clearcoat;
+    float invTotalWt = 1.0f / (w.diffPr + w.dielectricPr + w.metalPr + w.glassPr + w.clearCtPr);
+    w.diffPr *= invTotalWt;
+    w.dielectricPr *= invTotalWt;
+    w.metalPr *= invTotalWt;
+    w.glassPr *= invTotalWt;
+    w.clearCtPr *= invTotalWt;
+    return w;
+}
+
+PT_DEV v3 eval_diffuse(const Material& mat, v3 Csheen, v3 V, v3 L, v3 H, float& pdf)
+{
+    pdf = 0.0f;
+    if (L.z <= 0.0f) return mk3(0.0f);
+    float LDotH = dot3(L, H);
+    float Rr = 2.0f * mat.roughness * LDotH * LDotH;
+    float FL = schlick_weight(L.z);
+    float FV = schlick_weight(V.z);
+    float Fretro = Rr * (FL + FV + FL * FV * (Rr - 1.0f));
+    float Fd = (1.0f - 0.5f * FL) * (1.0f - 0.5f * FV);
+    float Fss90 = 0.5f * Rr;
+    float Fss = pt_lerp(1.0f, Fss90, FL) * pt_lerp(1.0f, Fss90, FV);
+    float ss = 1.25f * (Fss * (1.0f / (L.z + V.z) - 0.5f) + 0.5f);
+    float FH = schlick_weight(LDotH);
+    v3 Fsheen = FH * mat.sheen * Csheen;
+    pdf = L.z * PT_INV_PI;
+    return PT_INV_PI * mat.baseColor * pt_lerp(Fd + Fretro, ss, mat.subsurface) + Fsheen;
+}
+
+PT_DEV v3 eval_microfacet_reflection(const Material& mat, v3 V, v3 L, v3 H, v3 F, float& pdf)
+{
+    pdf = 0.0f;
+    if (L.z <= 0.0f) return mk3(0.0f);
+    float D = gtr2_aniso(H.z, H.x, H.y, mat.ax, mat.ay);
+    float G1 = smith_g_aniso(pt_abs(V.z), V.x, V.y, mat.ax, mat.ay);
+    float G2 = G1 * smith_g_aniso(pt_abs(L.z), L.x, L.y, mat.ax, mat.ay);
+    pdf = G1 * D / (4.0f * V.z);
+    return F * D * G2 / (4.0f * L.z * V.z);
+}
+
+PT_DEV v3 eval_microfacet_refraction(const Material& mat, float eta, v3 V, v3 L, v3 H, v3 F, float& pdf)
+{
+    pdf = 0.0f;
+    if (L.z >= 0.0f) return mk3(0.0f);
+    float LDotH = dot3(L, H);
+    float VDotH = dot3(V, H);
+    float D = gtr2_aniso(H.z, H.x, H.y, mat.ax, mat.ay);
+    float G1 = smith_g_aniso(pt_abs(V.z), V.x, V.y, mat.ax, mat.ay);
+    float G2 = G1 * smith_g_aniso(pt_abs(L.z), L.x, L.y, mat.ax, mat.ay);
+    float denom = LDotH + VDotH * eta;
+    denom *= denom;
+    float eta2 = eta * eta;
+    float jacobian = pt_abs(LDotH) / denom;
+    pdf = G1 * pt_max(0.0f, VDotH) * D * jacobian / V.z;
+    v3 sq = mk3(pt_pow(mat.baseColor.x, 0.5f), pt_pow(mat.baseColor.y, 0.5f), pt_pow(mat.baseColor.z, 0.5f));
+    return sq * (1.0f - F) * D * G2 * pt_abs(VDotH) * jacobian * eta2 / pt_abs(L.z * V.z);
+}
+
+PT_DEV v3 eval_clearcoat(const Material& mat, v3 V, v3 L, v3 H, float& pdf)
+{
+    pdf = 0.0f;
+    if (L.z <= 0.0f) return mk3(0.0f);
+    float VDotH = dot3(V, H);
+    float F = pt_lerp(0.04f, 1.0f, schlick_weight(VDotH));
+    float D = gtr1(H.z, mat.clearcoatRoughness);
+    float G = smith_g(L.z, 0.25f) * smith_g(V.z, 0.25f);
+    float jacobian = 1.0f / (4.0f * VDotH);
+    pdf = D * H.z * jacobian;
+    return mk3(F) * D * G;
+}
+
+// util/brdf.hlsl:114-225.  V and L are world-space; onb = GetONB(N).
+PT_DEV v3 eval_brdf_onb(const Material& mat, v3 V, v3 L, const Onb& onb, float& pdf)
+{
+    pdf = 0.0f;
+    v3 f = mk3(0.0f);
+    V = onb_to_local(onb, V);
+    L = onb_to_local(onb, L);
+    v3 H;
+    if (L.z > 0.0f) H = normalize3(L + V);
+    else H = normalize3(L + V * mat.eta);
+    if (H.z < 0.0f) H = -H;
+
+    v3 Csheen, Cspec0;
+    float F0;
+    tint_colors(mat, mat.eta, F0, Csheen, Cspec0);
+    Lobes w = lobe_weights(mat, Cspec0, V.z);
+
+    bool refl = L.z * V.z > 0.0f;
+    float tmpPdf = 0.0f;
+    float VDotH = pt_abs(dot3(V, H));
+
+    if (w.diffPr > 0.0f && refl) {
+        f = f + eval_diffuse(mat, Csheen, V, L, H, tmpPdf) * w.dielectricWt;
+        pdf += tmpPdf * w.diffPr;
+    }
+    if (w.dielectricPr > 0.0f && refl) {
+        float F = 0.0f;
+        if (F0 != 1.0f && mat.ior != 0.0f) {
+            float invEta = pt_rcp(mat.ior);
+            float invF0 = 1.0f - F0;
+            invF0 = pt_rcp(invF0);
+            F = (dielectric_fresnel(VDotH, invEta) - F0) * invF0;
+        }
+        f = f + eval_microfacet_reflection(mat, V, L, H, lerp3(Cspec0, mk3(1.0f), F), tmpPdf) * w.dielectricWt;
+        pdf += tmpPdf * w.dielectricPr;
+    }
+    if (w.metalPr > 0.0f && refl) {
+        v3 F = lerp3(mat.baseColor, mk3(1.0f), schlick_weight(VDotH));
+        f = f + eval_microfacet_reflection(mat, V, L, H, F, tmpPdf) * w.metalWt;
+        pdf += tmpPdf * w.metalPr;
+    }
+    if (w.glassPr > 0.0f) {
+        float F = dielectric_fresnel(VDotH, mat.eta);
+        if (refl) {
+            f = f + eval_microfacet_reflection(mat, V, L, H, mk3(F), tmpPdf) * w.glassWt;
+            pdf += tmpPdf * w.glassPr * F;
+        } else {
+            f = f + eval_microfacet_refraction(mat, mat.eta, V, L, H, mk3(F), tmpPdf) * w.glassWt;
+            pdf += tmpPdf * w.glassPr * (1.0f - F);
+        }
+    }
+    if (w.clearCtPr > 0.0f && refl) {
+        f = f + eval_clearcoat(mat, V, L, H, tmpPdf) * 0.25f * mat.clearcoat;
+        pdf += tmpPdf * w.clearCtPr;
+    }
+    f = f * mat.occlusion;
+    return f * pt_abs(L.z);
+}
+
+PT_DEV v3 eval_brdf(const Material& mat, v3 V, v3 N, v3 L, float& pdf)                  // util/brdf.hlsl:227-238
+{
+    Onb onb = make_onb(N);
+    return eval_brdf_onb(mat, V, L, onb, pdf);
+}
+
+PT_DEV v3 sample_brdf(const Material& mat, v3 V, v3 N, v3& L, float& pdf, uint32_t& rng) // util/brdf.hlsl:240-340
+{
+    pdf = 0.0f;
+    float r1 = rnd(rng);
+    float r2 = rnd(rng);
+    Onb onb = make_onb(N);
+    V = onb_to_local(onb, V);
+    v3 Csheen, Cspec0;
+    float F0;
+    tint_colors(mat, mat.eta, F0, Csheen, Cspec0);
+    Lobes w = lobe_weights(mat, Cspec0, V.z);
+    float cdf0 = w.diffPr;
+    float cdf1 = cdf0 + w.dielectricPr;
+    float cdf2 = cdf1 + w.metalPr;
+    float cdf3 = cdf2 + w.glassPr;
+    float r3 = rnd(rng);
+    if (r3 < cdf0) {
+        L = cosine_sample_hemisphere(r1, r2);
+    } else if (r3 < cdf2) {
+        v3 H = sample_ggx_vndf(V, mat.ax, mat.ay, r1, r2);
+        if (H.z < 0.0f) H = -H;
+        L = normalize3(reflect3(-V, H));
+    } else if (r3 < cdf3) {
+        v3 H = sample_ggx_vndf(V, mat.ax, mat.ay, r1, r2);
+        float F = dielectric_fresnel(pt_abs(dot3(V, H)), mat.eta);
+        if (H.z < 0.0f) H = -H;
+        r3 = (r3 - cdf2) / (cdf3 - cdf2);
+        if (r3 < F) L = normalize3(reflect3(-V, H));
+        else L = normalize3(refract3(-V, H, mat.eta));
+    } else {
+        v3 H = sample_gtr1(mat.clearcoatRoughness, r1, r2);
+        if (H.z < 0.0f) H = -H;
+        L = normalize3(reflect3(-V, H));
+    }
+    L = onb_to_world(onb, L);
+    V = onb_to_world(onb, V);
+    return eval_brdf_onb(mat, V, L, onb, pdf);
+}
+
+// util/random.hlsl:34-41
+PT_DEV v3 random_cosine_hemisphere(v3 normal, uint32_t& rng)
+{
+    float theta = pt_acos(pt_sqrt(rnd(rng)));
+    float phi = 2.0f * PT_PI * rnd(rng);
+    Onb onb = make_onb(normal);
+    return pt_sin(theta) * (pt_cos(phi) * onb.x + pt_sin(phi) * onb.y + pt_cos(theta) * onb.z);
+}
+
+// util/sky.hlsl:90-129 (colour / basic sky; the environment-texture half is not built: SURVEY.md §8f N4)
+PT_DEV v4 sample_sky_radiance(const PTFrameParams& P, v3 direction, uint32_t rayDepth)
+{
+    v4 radiance = {0.0f, 0.0f, 0.0f, 0.0f};
+    float pdf = 1.0f / (4.0f * PT_PI);
+    float intensity = 1.0f;
+    if ((int32_t)rayDepth > 0) intensity = P.EnvironmentIntensity;
+    if (P.EnvironmentMode == PT_SKY_MODE_ENVIRONMENT) {
+        v3 col = mk3(P.EnvironmentColor[0], P.EnvironmentColor[1], P.EnvironmentColor[2]) * intensity;
+        radiance = {col.x, col.y, col.z, pdf};
+    } else if (P.EnvironmentMode == PT_SKY_MODE_BASIC) {
+        float a = pt_saturate(0.5f * (direction.y + 1.0f));
+        v3 blue = mk3(pt_pow(0.5f, 2.2f), pt_pow(0.7f, 2.2f), pt_pow(1.0f, 2.2f));
+        v3 col = (1.0f - a) * mk3(1.0f) + a * blue;
+        col = col * intensity;
+        radiance = {col.x, col.y, col.z, pdf};
+    }
+    return radiance;
+}
+
+// ------------------------------------------------------------------------------------------
+// next-event estimation, split into "prepare" (all RNG draws + the BSDF value that would be added if
+// the shadow ray is unoccluded) and the shadow ray itself, so that the shadow rays of a bounce can be
+// traced together with the next bounce ray in one traversal pass.  util/light.hlsl:7-173.
+// The BSDF is evaluated eagerly; a contribution is only ADDED when its ray is unoccluded, in the
+// reference's order (environment first, then the analytic light), so sums are bit-identical.
+// ------------------------------------------------------------------------------------------
+struct NeeRay { v3 dir; v3 contribution; uint32_t valid; };
+
+PT_DEV v3 nee_scatter_pos(const SurfHit& hit) { return hit.position + hit.normal * PT_EPSILON; }
+
+// environment half of DirectLight (:123-160, no environment texture)
+PT_DEV void nee_prepare_environment(const PTFrameParams& P, v3 rayDir, const SurfHit& hit, const Material& mat,
+                                    uint32_t& rng, NeeRay& out)
+{
+    out.valid = 0u;
+    out.contribution = mk3(0.0f);
+    if (P.EnvironmentMode != 0) return;
+    v3 Li = mk3(P.EnvironmentColor[0], P.EnvironmentColor[1], P.EnvironmentColor[2]) * P.EnvironmentIntensity;
+    float lightPdf = 1.0f / (4.0f * PT_PI);
+    v3 lightDir = normalize3(random_cosine_hemisphere(hit.normal, rng));
+    out.dir = lightDir;
+    out.valid = 1u;
+    float spdf = 0.0f;
+    v3 sf = eval_brdf(mat, -rayDir, hit.ffnormal, lightDir, spdf);
+    if (spdf > 0.0f) {
+        float misWeight = power_heuristic(lightPdf, spdf);
+        if (misWeight > 0.0f) out.contribution = misWeight * Li * sf / lightPdf;
+        else out.valid = 2u;       // ray is traced (the reference traces before evaluating) but adds nothing
+    } else out.valid = 2u;
+}
+
+// analytic-light half of DirectLight (:162-170) + SampleOneLight (:47-58) + EvalLight (:60-114)
+template <bool STATS>
+PT_DEV void nee_prepare_light(const DScene& S, v3 rayDir, const SurfHit& hit, const Material& mat, v3 scatterPos,
+                              uint32_t& rng, NeeRay& out, Counters& cn)
+{
+    out.valid = 0u;
+    out.contribution = mk3(0.0f);
+    if (!S.hasLights) return;
+    int32_t lightIndex = pt_f2i(rnd(rng) * (float)S.lightCount);
+    if (lightIndex > S.lightCount - 1) lightIndex = S.lightCount - 1;
+    DLight light = load_light(S, lightIndex);
+    if (STATS) cn.lightFetches++;
+    v3 lsNormal, lsDirection;
+    float lsDistance, lsPdf;
+    if (light.type == PT_LIGHT_TYPE_SPOT) {
+        lsNormal = normalize3(light.u);
+        lsDirection = -normalize3(scatterPos - light.position);
+        lsDistance = length3(light.position - scatterPos);
+        lsPdf = 0.0f;
+    } else if (light.type == PT_LIGHT_TYPE_RECTANGLE) {
+        float r1 = rnd(rng);
+        float r2 = rnd(rng);
+        v3 lightSurfacePos = light.position + light.u * r1 + light.v * r2;
+        lsDirection = lightSurfacePos - scatterPos;
+        lsDistance = length3(lsDirection);
+        float distSq = lsDistance * lsDistance;
+        lsDirection = lsDirection / lsDistance;
+        lsNormal = normalize3(cross3(light.u, light.v));
+        lsPdf = distSq / (light.area * pt_abs(dot3(lsNormal, lsDirection)));
+    } else if (light.type == PT_LIGHT_TYPE_POINT) {
+        lsNormal = normalize3(scatterPos - light.position);
+        lsDirection = -lsNormal;
+        lsDistance = length3(scatterPos - light.position);
+        lsPdf = 0.0f;
+    } else {
+        return;                 // SampleOneLight returns false: no shadow ray, no contribution
+    }
+    // EvalLight
+    float falloff = 1.0f;
+    if (lsDistance > light.range) falloff = 0.0f;
+    else {
+        float r = lsDistance / light.range;
+        float atten = pt_saturate(1.0f / (1.0f + 25.0f * r * r) * pt_saturate((1.0f - r) * 5.0f));
+        falloff *= atten;
+    }
+    if (light.type == PT_LIGHT_TYPE_RECTANGLE) {
+        float cosTheta = dot3(normalize3(-lsDirection), normalize3(lsNormal));
+        falloff = cosTheta < 0.0f ? 0.0f : falloff;
+    }
+    if (light.type == PT_LIGHT_TYPE_SPOT) {
+        float cosTheta = dot3(normalize3(-lsDirection), normalize3(lsNormal));
+        if (cosTheta < light.v.x) falloff = 0.0f;
+        else if (cosTheta > light.v.x && cosTheta < light.v.y) falloff *= (cosTheta - light.v.x) / (light.v.y - light.v.x);
+    }
+    v3 Li = light.emission * falloff;
+    out.dir = lsDirection;
+    out.valid = 1u;
+    float pdf = 0.0f;
+    v3 f = eval_brdf(mat, -rayDir, hit.normal, lsDirection, pdf);
+    float lightPdf = 1.0f;
+    if (lsPdf > 0.0f) lightPdf = lsPdf;
+    out.contribution = Li * f / lightPdf;
+}
+
+// ------------------------------------------------------------------------------------------
+// camera.  util/camera.hlsl:13-42, util/common.hlsl:285-341, PathTracer.compute:33-38
+// ------------------------------------------------------------------------------------------
+PT_DEV v4 mul44(const float* m, v4 v)      // Unity Matrix4x4 memory order (element (r,c) at c*4+r), column vector
+{
+    v4 r;
+    r.x = m[0] * v.x + m[4] * v.y + m[8] * v.z + m[12] * v.w;
+    r.y = m[1] * v.x + m[5] * v.y + m[9] * v.z + m[13] * v.w;
+    r.z = m[2] * v.x + m[6] * v.y + m[10] * v.z + m[14] * v.w;
+    r.w = m[3] * v.x + m[7] * v.y + m[11] * v.z + m[15] * v.w;
+    return r;
+}
+
+PT_DEV void concentric_sample_disk(float u1, float u2, float& dx, float& dy)
+{
+    float sx = 2.0f * u1 - 1.0f;
+    float sy = 2.0f * u2 - 1.0f;
+    if (sx == 0.0f && sy == 0.0f) { dx = 0.0f; dy = 0.0f; return; }
+    float r, theta;
+    if (sx >= -sy) {
+        if (sx > sy) { r = sx; theta = sy > 0.0f ? sy / r : 8.0f + sy / r; }
+        else { r = sy; theta = 2.0f - sx / r; }
+    } else {
+        if (sx <= sy) { r = -sx; theta = 4.0f - sy / r; }
+        else { r = -sy; theta = 6.0f + sx / r; }
+    }
+    theta *= PT_PI / 4.0f;
+    dx = r * pt_cos(theta);
+    dy = r * pt_sin(theta);
+}
+
+// One camera sample: two jitter draws (left to right), optional two lens draws.  PathTracer.compute:68-75
+PT_DEV void generate_camera_ray(const PTFrameParams& P, uint32_t pixelX, uint32_t pixelY, uint32_t& rng, v3& origin, v3& direction)
+{
+    float g0 = rnd(rng);
+    float g1 = rnd(rng);
+    float gr = pt_sqrt(-2.0f * pt_log(pt_max(1e-38f, g0)));
+    float gtheta = 2.0f * PT_PI * g1;
+    float gx = gr * pt_cos(gtheta), gy = gr * pt_sin(gtheta);
+    float pcx = (float)pixelX + (0.5f + PT_AA_SIGMA * gx);
+    float pcy = (float)pixelY + (0.5f + PT_AA_SIGMA * gy);
+
+    v4 o4 = mul44(P.CamToWorld, v4{0.0f, 0.0f, 0.0f, 1.0f});
+    origin = mk3(o4.x, o4.y, o4.z);
+    float uvx = pcx / (float)P.OutputWidth * 2.0f - 1.0f;
+    float uvy = pcy / (float)P.OutputHeight * 2.0f - 1.0f;
+    v4 d4 = mul44(P.CamInvProj, v4{uvx, uvy, 0.0f, 1.0f});
+    v4 w4 = mul44(P.CamToWorld, v4{d4.x, d4.y, d4.z, 0.0f});
+    direction = normalize3(mk3(w4.x, w4.y, w4.z));
+    if (P.Aperture > 0.0f && P.FocalLength > 0.0f) {
+        float sampleLensU = rnd(rng);
+        float sampleLensV = rnd(rng);
+        float lensU, lensV;
+        concentric_sample_disk(sampleLensU, sampleLensV, lensU, lensV);
+        float lensRadius = P.Aperture * 0.5f;
+        lensU *= lensRadius;
+        lensV *= lensRadius;
+        float ft = P.FocalLength;
+        v3 focalPoint = origin + direction * ft;
+        v4 l4 = mul44(P.CamToWorld, v4{lensU, lensV, 0.0f, 1.0f});
+        origin = mk3(l4.x, l4.y, l4.z);
+        direction = normalize3(focalPoint - origin);
+    }
+}
