@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: Mrays/s of the path-tracing hot path at 1920x1080, 8 spp (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1 is launched by torch.distributed.run)
+
+A "step" is one progressive pass (one DispatchCompute of the reference, PathTracer.cs:251) over the whole
+1920x1080 frame at 8 samples per pixel: step k uses CurrentSample = 8k, RngSeedRoot_k = 0x12345678 + k*0x9E3779B9
+and the previous step's frame as AccumulatedOutput (SURVEY.md 8d, config C5's pass schedule).  Scene buffers and
+frames are resident in HBM before the timed region.  One ray = one RayIntersectBvh call (closest-hit or NEE
+shadow ray); the count comes from the kernels' own always-on counters, which the parity tests pin to the oracle's.
+
+N > 1: one process per GPU; the frame is sharded as interleaved 16x16-pixel blocks (PTSetTileOwnership), every
+rank renders only its blocks and the partial frames are summed onto rank 0 with ONE RCCL reduce per step (exact:
+non-owned pixels are zeros).  The total work is fixed as N grows -> "scaling": "strong".
+
+Rank 0 prints ONE JSON line.  `roofline` prices the render kernel against the 8 TB/s HBM peak with ALGORITHMIC
+bytes (SURVEY.md 8d formula over the kernel's own node/triangle/attribute/material/texel counters) divided by the
+kernel's mean duration measured with HIP events on the stream it is launched on.  `cpu_baseline` times the
+reference's tinybvh CPU walkers (oracle/_ref, compiled from /root/reference) on a bounded sample of the very rays
+of this workload, on the host cores of this box.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from unity_webgpu_pathtracer_amd import scenes  # noqa: E402
+from unity_webgpu_pathtracer_amd.pathtracer import PathTracer  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+SEED0, SEED_STEP = 0x12345678, 0x9E3779B9
+
+WORKLOADS = {
+    # BASELINE.json configs[3]: the configuration the >= 1 Gray/s target is quoted on
+    "sponza": dict(scene="sponza", kw=dict(tex_size=1024, detail=1.0), desc="Sponza-class atrium (~250k tris, 24 textured Disney materials, 2 rect lights + sky)"),
+    "bunny": dict(scene="bunny", kw={}, desc="bunny-class displaced icosphere (69,620 tris) in the Cornell box"),
+    "cornell": dict(scene="cornell", kw={}, desc="Cornell box (8 tris, 1 rectangle light)"),
+}
+
+
+def seed_of(step):
+    return (SEED0 + step * SEED_STEP) & 0xFFFFFFFF
+
+
+def cpu_baseline(scene, width, height, spp, pt, budget_rays=1_500_000):
+    """Reference tinybvh traversal (BVH::Intersect / IsOccluded, scalar build as the plugin ships it) over the
+    exact rays the oracle traces for a bounded sample of this workload's first pass."""
+    from oracle import pyoracle     # checker: allowed here (cpu_baseline leg only)
+    ref = pyoracle.load_ref_tinybvh()
+    if ref is None:
+        return None
+    b = pyoracle.SceneBuffers(scene, pt._bvhScene.bvh_nodes, pt._bvhScene.bvh_tris)
+    p = scenes.frame_params(scene, width, height, spp=spp, current_sample=0, seed=seed_of(0))
+    # sample: a 3x3 grid of 48x24-pixel windows spread over the frame
+    rays = []
+    t0 = time.time()
+    ww, wh = min(48, width), min(24, height)
+    for gy in range(3):
+        for gx in range(3):
+            x0 = int((gx + 0.5) * width / 3) - ww // 2
+            y0 = int((gy + 0.5) * height / 3) - wh // 2
+            _, _, dump = pyoracle.render(b, p, window=(x0, y0, x0 + ww, y0 + wh), ray_dump_capacity=budget_rays // 9)
+            rays.append(dump)
+    rays = np.concatenate(rays)
+    gen_s = time.time() - t0
+    n = rays.shape[0]
+    flat = np.zeros((n, 8), dtype=np.float32)
+    flat[:, 0:3] = rays["origin"]
+    flat[:, 3:6] = rays["direction"]
+    flat[:, 6] = rays["tmax"]
+    flat[:, 7] = rays["kind"]
+    verts = np.ascontiguousarray(scene.vertices, dtype=np.float32)
+    build_ms = C.c_double()
+    h = ref.ref_bvh_build(verts.ctypes.data_as(C.c_void_p), scene.tri_count, C.byref(build_ms))
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    ref.ref_bvh_trace(h, flat.ctypes.data_as(C.c_void_p), n, cores, None, None)         # warm
+    total, reps = 0.0, 0
+    while total < 3.0 and reps < 50:
+        total += ref.ref_bvh_trace(h, flat.ctypes.data_as(C.c_void_p), n, cores, None, None)
+        reps += 1
+    one = ref.ref_bvh_trace(h, flat.ctypes.data_as(C.c_void_p), min(n, 200_000), 1, None, None)
+    ref.ref_bvh_destroy(h)
+    return {
+        "value": round(n * reps / total / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "reference",
+        "sample": (f"{n} rays (closest-hit + NEE shadow) traced by the oracle for nine {ww}x{wh}-pixel windows of pass 0 of this "
+                   f"workload, x{reps} repeats; tinybvh BVH::Intersect/IsOccluded, scalar binned-SAH build {build_ms.value:.0f} ms; "
+                   f"single thread {min(n, 200_000) / one / 1e6:.3f} Mrays/s; oracle ray generation {gen_s:.1f} s"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="sponza", choices=sorted(WORKLOADS))
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=8)
+    ap.add_argument("--bounces", type=int, default=4)
+    ap.add_argument("--schedule", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads reported under 'other_workloads'")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if distributed:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    W, H, SPP = args.width, args.height, args.spp
+
+    def run_workload(name, steps, warmup, full):
+        wl = WORKLOADS[name]
+        scene = scenes.make_scene(wl["scene"], **wl["kw"])
+        pt = PathTracer(scene, device=local_rank, width=W, height=H, samplesPerPass=SPP, maxRayBounces=args.bounces,
+                        rank=rank, world_size=world)
+        if args.schedule:
+            pt.set_schedule(args.schedule)
+        frames = [torch.zeros((H, W, 4), dtype=torch.float32, device=device) for _ in range(2)]
+        ext = torch.cuda.ExternalStream(pt.stream(), device=device)
+        torch.cuda.synchronize(device)
+
+        def step(k, cur):
+            p = scenes.frame_params(scene, W, H, spp=SPP, current_sample=k * SPP, seed=seed_of(k), max_bounces=args.bounces)
+            pt.render_pass_to(p, frames[cur].data_ptr(), frames[1 - cur].data_ptr() if k > 0 else 0)
+            if distributed:
+                with torch.cuda.stream(ext):
+                    dist.reduce(frames[cur], dst=0, op=dist.ReduceOp.SUM)      # RCCL over xGMI, once per frame
+
+        def sync_all():
+            pt.synchronize()
+            torch.cuda.synchronize(device)
+            if distributed:
+                dist.barrier()
+                torch.cuda.synchronize(device)
+
+        cur = 0
+        for k in range(warmup):
+            step(k, cur)
+            cur = 1 - cur
+        sync_all()
+        pt.reset_stats()
+        pt.set_profiling(True)
+        pt.reset_timings()
+        sync_all()
+        t0 = time.perf_counter()
+        for k in range(warmup, warmup + steps):
+            step(k, cur)
+            cur = 1 - cur
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        st = pt.stats()
+        tm = pt.timings()
+        pt.set_profiling(False)
+        rays = torch.tensor([st.rays, st.closestHitRays, st.shadowRays, st.paths], dtype=torch.float64, device=device)
+        el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        if distributed:
+            dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+        total_rays = float(rays[0].item())
+        res = {
+            "mrays_per_s": total_rays / elapsed / 1e6,
+            "ms_per_step": elapsed / steps * 1e3,
+            "rays_per_step": total_rays / steps,
+            "closest_hit_rays": float(rays[1].item()) / steps, "shadow_rays": float(rays[2].item()) / steps,
+            "msamples_per_s": float(rays[3].item()) / elapsed / 1e6,
+            "kernel_ms": tm.kernelMsTotal / max(1, tm.passes),
+            "tris": scene.tri_count,
+        }
+        if full and rank == 0:
+            # algorithmic bytes: replay the same timed steps once, untimed, with the full-counter kernel variant
+            pt.set_stats_level(1)
+            pt.reset_stats()
+            c2 = cur
+            for k in range(warmup, warmup + steps):
+                p = scenes.frame_params(scene, W, H, spp=SPP, current_sample=k * SPP, seed=seed_of(k), max_bounces=args.bounces)
+                pt.render_pass_to(p, frames[c2].data_ptr(), frames[1 - c2].data_ptr() if k > 0 else 0)
+                c2 = 1 - c2
+            pt.synchronize()
+            fs = pt.stats()
+            pt.set_stats_level(0)
+            res["alg_bytes_per_launch"] = fs.algorithmic_bytes() / steps
+            res["counters_per_launch"] = {k: v / steps for k, v in fs.as_dict().items() if k not in ("maxStackDepth", "stackOverflows")}
+            res["max_stack_depth"] = int(fs.maxStackDepth)
+        if distributed and full:
+            dist.barrier()
+        res["_pt"], res["_scene"] = pt, scene
+        return res
+
+    main_res = run_workload(args.workload, args.steps, args.warmup, full=True)
+    out = None
+    if rank == 0:
+        kernel_s = main_res["kernel_ms"] / 1e3
+        achieved = main_res["alg_bytes_per_launch"] / kernel_s / 1e9 if kernel_s > 0 else 0.0
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tj):
+            try:
+                rec = json.load(open(tj))
+                if rec.get("workload") == args.workload and rec.get("n_gpus", 1) == world:
+                    traffic = rec.get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s at 1920x1080, 8 spp", "value": round(main_res["mrays_per_s"], 3), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(main_res["ms_per_step"], 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload]['desc']}, {W}x{H}, {SPP} spp/pass, depth {args.bounces}, "
+                                   f"progressive passes (CurrentSample = 8k)",
+                       "tris": main_res["tris"], "rays_per_step": round(main_res["rays_per_step"]),
+                       "msamples_per_s": round(main_res["msamples_per_s"], 3), "schedule": args.schedule,
+                       "sharding": "interleaved 16x16 blocks, one RCCL reduce per frame" if distributed else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                         "kernel": "pt_megakernel" if args.schedule == 0 else f"schedule{args.schedule}",
+                         "kernel_ms": round(main_res["kernel_ms"], 4),
+                         "algorithmic_bytes_per_launch": round(main_res["alg_bytes_per_launch"]),
+                         "note": "rank-0 kernel; working set is Infinity-Cache resident, the path is latency/divergence-bound (DESIGN.md)"},
+        }
+    if not args.no_extra and not distributed:
+        extra = {}
+        for name in WORKLOADS:
+            if name == args.workload:
+                continue
+            r = run_workload(name, max(2, args.steps // 2), 1, full=False)
+            r["_pt"].close()
+            extra[name] = {"mrays_per_s": round(r["mrays_per_s"], 3), "ms_per_step": round(r["ms_per_step"], 4), "tris": r["tris"]}
+        if out is not None:
+            out["other_workloads"] = extra
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        wl = WORKLOADS[args.workload]
+        scene = main_res.get("_scene")
+        pt = main_res.get("_pt")
+        if pt is None:
+            scene = scenes.make_scene(wl["scene"], **wl["kw"])
+            pt = PathTracer(scene, device=local_rank, width=W, height=H, samplesPerPass=SPP)
+        try:
+            out["cpu_baseline"] = cpu_baseline(scene, W, H, SPP, pt)
+        except Exception as e:       # the checker being unavailable must not hide the GPU number
+            out["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "reference", "sample": f"unavailable: {e}"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

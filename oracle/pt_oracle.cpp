@@ -117,6 +117,7 @@ struct Ctx {
     const PTFrameParams* P;
     PTStats st;
     bool shadowAnyHit;
+    bool nanRayEarlyOut;
     OracleOptions* opt;     // ray dump target (single-threaded use)
 };
 
@@ -246,6 +247,14 @@ bool RayIntersectBvh(Ctx& c, const Ray& ray, RayHit& hit, bool isShadowRay)
         d.origin[0] = ray.origin.x; d.origin[1] = ray.origin.y; d.origin[2] = ray.origin.z;
         d.direction[0] = ray.direction.x; d.direction[1] = ray.direction.y; d.direction[2] = ray.direction.z;
         d.tmax = hit.distance; d.kind = isShadowRay ? 1.0f : 0.0f;
+    }
+
+    // Optional (counting variant only): a ray carrying a NaN can never hit a triangle, yet passes every slab
+    // test, so the reference walks the whole tree for it; the GPU kernels return the miss at once.
+    if (c.nanRayEarlyOut && (pt_isnan(ray.origin.x) || pt_isnan(ray.origin.y) || pt_isnan(ray.origin.z) ||
+                             pt_isnan(ray.direction.x) || pt_isnan(ray.direction.y) || pt_isnan(ray.direction.z))) {
+        hit.steps = 0;
+        return hit.distance < PT_FAR_PLANE;
     }
 
     uint32_t stackX[PT_BVH_STACK_SIZE], stackY[PT_BVH_STACK_SIZE];
@@ -1112,6 +1121,7 @@ int oracle_render(const PTSceneDesc* scene, const PTFrameParams* params, const f
         Ctx c;
         c.S = &S; c.P = params; memset(&c.st, 0, sizeof(PTStats));
         c.shadowAnyHit = opt->shadowAnyHit != 0;
+        c.nanRayEarlyOut = opt->shadowAnyHit != 0;
         c.opt = opt->rayDump ? opt : nullptr;
         for (;;) {
             int y = nextRow.fetch_add(1);
@@ -1150,7 +1160,7 @@ int oracle_trace(const PTSceneDesc* scene, const OracleRay* rays, uint64_t n, fl
     PTFrameParams P;
     memset(&P, 0, sizeof(P));
     Ctx c;
-    c.S = &S; c.P = &P; memset(&c.st, 0, sizeof(PTStats)); c.shadowAnyHit = false; c.opt = nullptr;
+    c.S = &S; c.P = &P; memset(&c.st, 0, sizeof(PTStats)); c.shadowAnyHit = false; c.nanRayEarlyOut = false; c.opt = nullptr;
     for (uint64_t i = 0; i < n; i++) {
         Ray r = {V3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]),
                  V3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2])};
@@ -1201,7 +1211,7 @@ static Material MaterialFromData(const float* material, f3 V, f3 N, float eta)
     PTFrameParams P;
     memset(&P, 0, sizeof(P));
     Ctx c;
-    c.S = &S; c.P = &P; memset(&c.st, 0, sizeof(PTStats)); c.shadowAnyHit = false; c.opt = nullptr;
+    c.S = &S; c.P = &P; memset(&c.st, 0, sizeof(PTStats)); c.shadowAnyHit = false; c.nanRayEarlyOut = false; c.opt = nullptr;
     PTMaterialData md;
     memcpy(&md, material, sizeof(md));
     Ray ray = {V3(0.0f), -V};

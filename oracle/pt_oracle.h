@@ -36,9 +36,11 @@ typedef struct OracleRay {
 typedef struct OracleOptions {
     int32_t  x0, y0, x1, y1;      /* pixel window [x0,x1) x [y0,y1); all zero = whole frame        */
     int32_t  threads;             /* worker threads (rows are interleaved); <= 0 -> 1               */
-    int32_t  shadowAnyHit;        /* 0 = reference-faithful full traversal for shadow rays,
-                                     1 = stop at the first accepted triangle (same boolean; changes
-                                     only nodeVisits / triTests, used to check the GPU's counters)  */
+    int32_t  shadowAnyHit;        /* 0 = reference-faithful traversal;
+                                     1 = count work as the GPU kernels do it: shadow rays stop at the first
+                                     accepted triangle, and rays carrying a NaN return their (certain) miss
+                                     without walking the tree.  Same frame bit for bit; only nodeVisits /
+                                     triTests / maxStackDepth change (used to check the GPU's counters)  */
     int32_t  tileRank, tileWorld; /* PTSetTileOwnership emulation: non-owned pixels are written 0   */
     OracleRay* rayDump;           /* optional: receives up to rayDumpCapacity rays (single thread!) */
     uint64_t rayDumpCapacity;

@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Generates the committed golden fixtures (run in the build container, where /root/reference exists).
+
+  cwbvh_*.npz   byte-exact CWBVH node/triangle dumps and TLAS dumps produced by the REFERENCE plugin
+                (Assets/Plugins/Web/plugin.cpp compiled in place -> oracle/_ref), together with their inputs.
+  trace_*.npz   rays + (t, prim) from the REFERENCE's tinybvh CPU walker BVH::Intersect (oracle/ref_driver.cpp).
+  frame_*.npz   frames rendered by the CPU oracle (regression pin of the restatement itself; the reference's
+                shader cannot be executed here, so these are NOT reference outputs -- see DESIGN.md).
+
+Fixtures are data only (inputs and expected outputs); no reference source text is stored.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import pyoracle  # noqa: E402
+from unity_webgpu_pathtracer_amd import abi, scenes  # noqa: E402
+
+
+def soup(rng, n, spread=10.0, size=1.0):
+    c = rng.uniform(-spread, spread, (n, 1, 3))
+    v = c + rng.normal(0, size, (n, 3, 3))
+    out = np.zeros((n * 3, 4), np.float32)
+    out[:, :3] = v.reshape(-1, 3)
+    return out
+
+
+def main():
+    pyoracle.build(ref=True)
+    rng = np.random.RandomState(20251226)
+    cases = {
+        "cornell": scenes.cornell_box().vertices,
+        "soup1": soup(rng, 1), "soup3": soup(rng, 3), "soup4": soup(rng, 4), "soup300": soup(rng, 300, 6.0, 0.5),
+        "flat_grid": scenes.SoupBuilder(),
+    }
+    sb = cases.pop("flat_grid")
+    sb.quad((-2, 0, -2), (4, 0, 0), (0, 0, 4), (0, 1, 0), 6, 6, 0)
+    cases["flat_grid72"] = sb.finish()[0]
+    dup = np.zeros((60, 4), np.float32)
+    dup[:, :3] = np.tile(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32), (20, 1))
+    cases["identical20"] = dup
+    for name, v in cases.items():
+        nodes, tris = pyoracle.ref_build_cwbvh(v)
+        np.savez_compressed(os.path.join(HERE, f"cwbvh_{name}.npz"), vertices=v, nodes=nodes, tris=tris)
+        print(f"cwbvh_{name}: {v.shape[0] // 3} tris -> {nodes.nbytes} node bytes, {tris.nbytes} tri bytes")
+    for n in (1, 2, 5, 40):
+        inst = np.zeros(n, abi.BLAS_INSTANCE)
+        c = rng.uniform(-20, 20, (n, 3))
+        e = rng.uniform(0.1, 3, (n, 3))
+        inst["aabbMin"] = c - e
+        inst["aabbMax"] = c + e
+        nodes, idx = pyoracle.ref_build_tlas(inst)
+        np.savez_compressed(os.path.join(HERE, f"tlas_{n}.npz"), instances=inst.view(np.uint8), nodes=nodes, indices=idx)
+        print(f"tlas_{n}: {nodes.nbytes} node bytes")
+
+    # reference CPU traversal known-answers on a small scene
+    s = scenes.material_zoo()
+    ref = pyoracle.load_ref_tinybvh()
+    import ctypes as C
+    verts = np.ascontiguousarray(s.vertices, np.float32)
+    h = ref.ref_bvh_build(verts.ctypes.data_as(C.c_void_p), s.tri_count, None)
+    n = 4000
+    o = rng.uniform(-3.5, 3.5, (n, 3)).astype(np.float32)
+    o[:, 1] = rng.uniform(0.2, 4.0, n)
+    d = rng.normal(0, 1, (n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, 0:3], rays[:, 3:6], rays[:, 6] = o, d, 1e5
+    rays[n // 2:, 7] = 1.0
+    t = np.zeros(n, np.float32)
+    prim = np.zeros(n, np.uint32)
+    ref.ref_bvh_trace(h, rays.ctypes.data_as(C.c_void_p), n, 1, t.ctypes.data_as(C.c_void_p), prim.ctypes.data_as(C.c_void_p))
+    ref.ref_bvh_destroy(h)
+    np.savez_compressed(os.path.join(HERE, "trace_zoo.npz"), rays=rays, t=t, prim=prim)
+    print("trace_zoo:", n, "rays, hits", int((prim != 0xFFFFFFFF).sum()))
+
+    # oracle regression frames
+    from unity_webgpu_pathtracer_amd import plugin
+    for name, sc, w, hgt, spp, seed in (("cornell", scenes.cornell_box(), 32, 32, 2, 0x12345678),
+                                       ("zoo", scenes.material_zoo(), 40, 24, 2, 0xC0FFEE)):
+        nodes, tris = plugin.build_cwbvh(sc.vertices)
+        b = pyoracle.SceneBuffers(sc, nodes, tris)
+        p = scenes.frame_params(sc, w, hgt, spp=spp, seed=seed)
+        img, st = pyoracle.render(b, p, threads=1)
+        np.savez_compressed(os.path.join(HERE, f"frame_{name}.npz"), frame=img, width=w, height=hgt, spp=spp, seed=seed,
+                            stats=np.array([st.as_dict()[k] for k in sorted(st.as_dict())], dtype=np.uint64),
+                            stat_names=np.array(sorted(st.as_dict())))
+        print(f"frame_{name}: mean {img[..., :3].mean():.5f}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,74 @@
+"""The N > 1 path on CPU: two processes over gloo shard a frame as interleaved 16x16 blocks, each produces its partial
+frame (here with the oracle standing in for the GPU kernels, which cannot run in this container), and ONE reduce
+onto rank 0 reproduces the single-process frame bit for bit -- the same collective bench.py issues over RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pyoracle
+    from unity_webgpu_pathtracer_amd import distributed, plugin, scenes
+    s = scenes.cornell_box()
+    nodes, tris = plugin.build_cwbvh(s.vertices)
+    b = pyoracle.SceneBuffers(s, nodes, tris)
+    w, h = 80, 48
+    frames = [None, None]
+    cur = 0
+    for k in range(2):                                   # two progressive passes, each rank keeps only its own history
+        p = scenes.frame_params(s, w, h, spp=2, current_sample=2 * k, seed=(0x12345678 + k * 0x9E3779B9) & 0xFFFFFFFF)
+        part, _ = pyoracle.render(b, p, accumulated=frames[1 - cur], tile_rank=rank, tile_world=world, threads=1)
+        frames[cur] = part
+        t = torch.from_numpy(part.copy())
+        distributed.reduce_frame(t, dst=0)
+        cur = 1 - cur
+    if rank == 0:
+        np.save(out_path, t.numpy())
+    counts = torch.tensor(distributed.owned_pixel_counts(w, h, world))
+    assert int(counts.sum()) == w * h
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_tile_sharding_is_bit_exact(tmp_path, oracle):
+    world = 2
+    out = str(tmp_path / "reduced.npy")
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    reduced = np.load(out)
+    from unity_webgpu_pathtracer_amd import plugin, scenes
+    s = scenes.cornell_box()
+    nodes, tris = plugin.build_cwbvh(s.vertices)
+    b = oracle.SceneBuffers(s, nodes, tris)
+    prev = None
+    for k in range(2):
+        p = scenes.frame_params(s, 80, 48, spp=2, current_sample=2 * k, seed=(0x12345678 + k * 0x9E3779B9) & 0xFFFFFFFF)
+        prev, _ = oracle.render(b, p, accumulated=prev)
+    assert np.array_equal(reduced.view(np.uint32), prev.view(np.uint32))
+
+
+def test_ownership_is_a_partition():
+    from unity_webgpu_pathtracer_amd import distributed
+    for world in (1, 2, 3, 4, 8):
+        total = sum(distributed.ownership_mask(1920, 1080, r, world).astype(np.int64) for r in range(world))
+        assert (total == 1).all()
+        counts = distributed.owned_pixel_counts(1920, 1080, world)
+        assert max(counts) - min(counts) <= 0.02 * 1920 * 1080 / world     # interleaving balances within 2 %

@@ -147,3 +147,21 @@ def test_tile_ownership_sums_to_full_frame(oracle):
         acc += part
         pt.close()
     assert np.array_equal(acc.view(np.uint32), f.view(np.uint32))
+
+
+def test_nan_nee_ray_is_a_cheap_miss(oracle):
+    """RandomFloat == 1.0 at the environment-NEE draw -> NaN shadow ray (util/random.hlsl:34-41).  The reference walks
+    the whole tree for it; the kernels return the certain miss at once.  Frame identical to the faithful oracle,
+    counters identical to the oracle's counting variant."""
+    s = scenes.sponza_atrium(tex_size=4, detail=0.15)
+    pt = PathTracer(s, width=8, height=8, samplesPerPass=1)
+    pt.set_stats_level(1)
+    p = pt.params(seed=0xED3B3E)
+    pt.render_pass(p)
+    gpu = pt.readback()
+    faithful, sf = _oracle_frame(oracle, pt, p)
+    fast, sq = _oracle_frame(oracle, pt, p, shadow_any_hit=True)
+    assert np.array_equal(gpu.view(np.uint32), faithful.view(np.uint32))
+    _stats_equal(pt.stats(), sq, ALL_COUNTERS)
+    assert sf.nodeVisits > sq.nodeVisits + 1000
+    pt.close()

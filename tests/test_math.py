@@ -1,0 +1,81 @@
+"""include/ptmi_math.h: the canonical elementary functions stay within a few ulp of libm, and the RNG
+reproduces the known-answer vectors computed from util/random.hlsl:5-16."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def _ulp_err(got, ref64):
+    ref32 = ref64.astype(np.float32)
+    ulp = np.spacing(np.abs(ref32)).astype(np.float64)
+    return np.abs(got.astype(np.float64) - ref64) / np.maximum(ulp, 1e-300)
+
+
+def _apply(lib, fn, x, y=None):
+    y = np.zeros_like(x) if y is None else y
+    return np.array([lib.oracle_math(fn, float(a), float(b)) for a, b in zip(x, y)], dtype=np.float32)
+
+
+@pytest.fixture(scope="module")
+def lib(oracle):
+    return oracle.load_oracle()
+
+
+def test_sin_cos(lib):
+    rng = np.random.RandomState(1)
+    x = rng.uniform(0.0, 6.3, 20000).astype(np.float32)          # the shader only passes angles in [0, 2pi]
+    assert np.abs(_apply(lib, 0, x) - np.sin(x.astype(np.float64))).max() < 1.5e-7
+    assert np.abs(_apply(lib, 1, x) - np.cos(x.astype(np.float64))).max() < 1.5e-7
+    big = rng.uniform(-2000.0, 2000.0, 5000).astype(np.float32)
+    assert np.abs(_apply(lib, 0, big) - np.sin(big.astype(np.float64))).max() < 2e-6
+
+
+def test_log_exp_pow_acos(lib):
+    rng = np.random.RandomState(2)
+    u = np.exp(-rng.uniform(0, 80, 20000)).astype(np.float32)
+    assert _ulp_err(_apply(lib, 2, u), np.log(u.astype(np.float64))).max() <= 2.0
+    assert _ulp_err(_apply(lib, 3, u), np.log2(u.astype(np.float64))).max() <= 3.0
+    e = rng.uniform(-125, 125, 20000).astype(np.float32)
+    assert _ulp_err(_apply(lib, 4, e), np.exp2(e.astype(np.float64))).max() <= 3.0
+    a = rng.uniform(-1, 1, 20000).astype(np.float32)
+    assert _ulp_err(_apply(lib, 6, a), np.arccos(a.astype(np.float64))).max() <= 3.0
+    b = rng.uniform(1e-6, 1.0, 5000).astype(np.float32)
+    y = rng.uniform(0, 1, 5000).astype(np.float32)
+    rel = np.abs(_apply(lib, 5, b, y).astype(np.float64) / np.power(b.astype(np.float64), y.astype(np.float64)) - 1)
+    assert rel.max() < 5e-6                                        # pow = exp2(y*log2(x)), as HLSL defines it
+
+
+def test_special_values(lib):
+    f = lambda fn, x, y=0.0: lib.oracle_math(fn, x, y)
+    assert f(2, 1.0) == 0.0 and f(4, 0.0) == 1.0 and f(6, 1.0) == 0.0
+    assert f(2, 0.0) == -np.inf and np.isnan(f(2, -1.0)) and np.isnan(f(6, 1.5))
+    assert f(5, 0.0, 0.5) == 0.0 and f(5, 0.25, 0.5) == 0.5 and f(5, 1.0, 2.2) == 1.0
+    assert f(4, -130.0) > 0 and f(4, 200.0) == np.inf
+    assert f(8, 4.0) == 2.0 and f(9, 4.0) == 0.25 and f(9, 0.0) == np.inf
+
+
+KNOWN = {   # state after each call : float returned
+    0x00000000: [(0xa8beea3c, 0.659163117), (0x0a2a1484, 0.039704591), (0x1e93be90, 0.119441897), (0x75134d09, 0.457325757)],
+    0x00000001: [(0xb94dd992, 0.723844171), (0x7d3246cc, 0.489048421), (0xcb994a9c, 0.795307815), (0x4dd1f399, 0.303984851)],
+    0x12345678: [(0x199714cb, 0.0999615639), (0xe91f039e, 0.910629511), (0x76c6835c, 0.463966578), (0xbc936622, 0.736624122)],
+    0xffffffff: [(0x982ff7a5, 0.594481945), (0xbefdfcf3, 0.746063054), (0x37723005, 0.216586113), (0xd7a537c4, 0.842364788)],
+}
+
+
+def test_rng_known_answers(lib):
+    for seed, seq in KNOWN.items():
+        s = C.c_uint32(seed)
+        for state, value in seq:
+            f = lib.oracle_random_float(C.byref(s))
+            assert s.value == state
+            assert np.float32(f) == np.float32(value)
+
+
+def test_rng_top_states_round_to_one(lib):
+    """(float)0xFFFFFF80 / 2^32 == 1.0: RandomFloat is inclusive of 1 -- the reason the light
+    pick is clamped and the reason NaN NEE directions exist (util/random.hlsl:34-41)."""
+    assert np.float32(0xFFFFFF7F) / np.float32(4294967296.0) < 1.0
+    assert np.float32(0xFFFFFF80) / np.float32(4294967296.0) == 1.0
+    # per-pixel seed example of SURVEY.md Appendix D: W = 256, pixel (10, 3), CurrentSample 0
+    assert (3 * 256 + 10) * (0 + 1) + 0x12345678 == 0x12345982

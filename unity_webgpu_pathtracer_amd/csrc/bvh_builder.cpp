@@ -15,7 +15,7 @@
 //     2. depth-first conversion to the Aila-Laine two-children-per-node layout
 //
 // The output is required to be BYTE-IDENTICAL to the reference plugin's (tests/test_bvh_builder.py
-// memcmp's it against oracle/_ref and against committed golden dumps), so every float operation below is
+// memcmp's it against the reference plugin compiled in place and against committed golden dumps), so every float operation below is
 // written in the order the reference evaluates it, float->int conversions use the x86 truncating forms
 // the reference's compiled code uses (out-of-range -> "integer indefinite"), and log2f/powf/ceilf/floorf
 // come from the same libm.  Compile with -ffp-contract=off.

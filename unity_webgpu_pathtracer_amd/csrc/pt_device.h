@@ -210,9 +210,18 @@ PT_DEV void intersect_triangle(const float4* __restrict__ tris, uint32_t triAddr
 
 // util/bvh.hlsl:126-199 for one lane.  ANYHIT = shadow ray: stops at the first accepted triangle
 // (ShadowRayIntersect only uses the boolean, util/bvh.hlsl:228-233, so the result is identical).
+//
+// A ray with a NaN in its origin or direction can never be accepted by IntersectTriangle (every product
+// with the NaN poisons `a` or `u`, and all its comparisons are false), but under HLSL/IEEE min-max
+// semantics its slab test passes for EVERY child (cmin = 0, cmax = tmax), so the reference walks the whole
+// tree for it.  Such rays do occur: RandomFloat returns exactly 1.0 for 128 of 2^32 states, which makes
+// RandomCosineHemisphere return the zero vector and normalize() turn it into NaN (util/random.hlsl:34-41,
+// util/light.hlsl:141) -- about two NEE rays per 1080p/8spp frame.  One lane visiting 45k nodes + 250k
+// triangles stalls its whole kernel for ~80 ms, so the miss is returned immediately (same result).
 template <bool STATS>
 PT_DEV void traverse_cwbvh(const DScene& S, v3 o, v3 d, bool anyHit, TraceHit& hit, TravStack& st, Counters& cn)
 {
+    if (pt_isnan(o.x) || pt_isnan(o.y) || pt_isnan(o.z) || pt_isnan(d.x) || pt_isnan(d.y) || pt_isnan(d.z)) return;
     v3 invDir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     uint32_t octinv4 = (7u - ((d.x < 0.0f ? 4u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 1u : 0u))) * 0x1010101u;
     uint32_t sp = 0;
