@@ -1,0 +1,12 @@
+#!/bin/bash
+# Run ON THE GPU BOX (through gpurun) from the repo root:  bash profiles/collect.sh r01
+# Three separate rocprofv3 runs of the same bench command: kernel trace + stats, then one --pmc pass per counter
+# (FETCH_SIZE and WRITE_SIZE do not fit one pass; --pmc is never combined with other trace domains).
+set -e
+TAG=${1:-r01}
+export TMPDIR=/tmp
+CMD="python3 bench.py --steps 4 --warmup 1 --no-extra --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_trace -- $CMD > gpurun_out/${TAG}_trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/${TAG}_fetch -- $CMD > gpurun_out/${TAG}_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/${TAG}_write -- $CMD > gpurun_out/${TAG}_write.log 2>&1
+tail -1 gpurun_out/${TAG}_trace.log | cut -c1-600
