@@ -42,10 +42,14 @@ ALL_COUNTERS = ["paths", "closestHitRays", "shadowRays", "nodeVisits", "triTests
                 "stackOverflows"]
 
 
-def test_c1_cornell_256_1spp(oracle):
+SCHEDULES = [0, 1]          # 0 = megakernel, 1 = wavefront (csrc/pt_wavefront.hip); both must be bit-identical to the oracle
+
+
+@pytest.mark.parametrize("schedule", SCHEDULES)
+def test_c1_cornell_256_1spp(oracle, schedule):
     """BASELINE.json configs[0]: Cornell box 256x256, 1 spp, depth 4."""
     s = scenes.cornell_box()
-    pt = PathTracer(s, width=256, height=256, samplesPerPass=1)
+    pt = PathTracer(s, width=256, height=256, samplesPerPass=1, schedule=schedule)
     pt.set_stats_level(1)
     p = pt.params(seed=0x12345678)
     pt.render_pass(p)
@@ -57,15 +61,16 @@ def test_c1_cornell_256_1spp(oracle):
     pt.close()
 
 
+@pytest.mark.parametrize("schedule", SCHEDULES)
 @pytest.mark.parametrize("name,kw,w,h,spp", [
     ("zoo", {}, 160, 120, 4),
     ("zoo", {"basic_sky": True}, 96, 64, 2),
     ("sponza", {"tex_size": 32, "detail": 0.15}, 160, 96, 2),
     ("furnace", {}, 64, 64, 4),
 ])
-def test_small_scenes_bit_exact(oracle, name, kw, w, h, spp):
+def test_small_scenes_bit_exact(oracle, name, kw, w, h, spp, schedule):
     s = scenes.make_scene(name, **kw)
-    pt = PathTracer(s, width=w, height=h, samplesPerPass=spp)
+    pt = PathTracer(s, width=w, height=h, samplesPerPass=spp, schedule=schedule)
     pt.set_stats_level(1)
     p = pt.params(seed=0xC0FFEE)
     pt.render_pass(p)
@@ -77,10 +82,11 @@ def test_small_scenes_bit_exact(oracle, name, kw, w, h, spp):
     pt.close()
 
 
-def test_progressive_accumulation(oracle):
+@pytest.mark.parametrize("schedule", SCHEDULES)
+def test_progressive_accumulation(oracle, schedule):
     """Two passes through the C# host contract (PathTracer.cs:268-272): pass 2 reads pass 1 as AccumulatedOutput."""
     s = scenes.cornell_box()
-    pt = PathTracer(s, width=128, height=128, samplesPerPass=4)
+    pt = PathTracer(s, width=128, height=128, samplesPerPass=4, schedule=schedule)
     seeds = [0x12345678, (0x12345678 + 0x9E3779B9) & 0xFFFFFFFF]
     p0 = pt.params(seeds[0])
     pt.OnRenderImage(seeds[0])
@@ -97,10 +103,11 @@ def test_progressive_accumulation(oracle):
     pt.close()
 
 
-def test_firefly_no_rr_depth1(oracle):
+@pytest.mark.parametrize("schedule", SCHEDULES)
+def test_firefly_no_rr_depth1(oracle, schedule):
     s = scenes.material_zoo()
     pt = PathTracer(s, width=96, height=64, samplesPerPass=2, maxRayBounces=1, useRussianRoulette=False,
-                    fireflyFilter=True, maxFireflyLuminance=2.0)
+                    fireflyFilter=True, maxFireflyLuminance=2.0, schedule=schedule)
     p = pt.params(seed=7)
     pt.render_pass(p)
     gpu = pt.readback()
@@ -110,12 +117,13 @@ def test_firefly_no_rr_depth1(oracle):
     pt.close()
 
 
-def test_reference_dispatch_edge_pixels(oracle):
+@pytest.mark.parametrize("schedule", SCHEDULES)
+def test_reference_dispatch_edge_pixels(oracle, schedule):
     """Sizes that are not multiples of 8: ceil coverage renders everything; the C# host's floor-division
     dispatch (PathTracer.cs:207-208) leaves the edge pixels untouched."""
     s = scenes.cornell_box()
     for ref_dispatch in (False, True):
-        pt = PathTracer(s, width=100, height=70, samplesPerPass=1, reference_dispatch=ref_dispatch)
+        pt = PathTracer(s, width=100, height=70, samplesPerPass=1, reference_dispatch=ref_dispatch, schedule=schedule)
         p = pt.params(seed=99)
         pt.render_pass(p)
         gpu = pt.readback()
@@ -127,7 +135,8 @@ def test_reference_dispatch_edge_pixels(oracle):
         pt.close()
 
 
-def test_tile_ownership_sums_to_full_frame(oracle):
+@pytest.mark.parametrize("schedule", SCHEDULES)
+def test_tile_ownership_sums_to_full_frame(oracle, schedule):
     """PTSetTileOwnership: the per-rank partial frames sum (exact zeros elsewhere) to the single-GPU frame."""
     s = scenes.material_zoo()
     w, h, spp = 112, 80, 2
@@ -139,7 +148,7 @@ def test_tile_ownership_sums_to_full_frame(oracle):
     world = 3
     acc = np.zeros_like(f)
     for rank in range(world):
-        pt = PathTracer(s, width=w, height=h, samplesPerPass=spp, rank=rank, world_size=world)
+        pt = PathTracer(s, width=w, height=h, samplesPerPass=spp, rank=rank, world_size=world, schedule=schedule)
         pt.render_pass(p)
         part = pt.readback()
         ref, _ = _oracle_frame(oracle, pt, p, tile_rank=rank, tile_world=world)
@@ -149,12 +158,13 @@ def test_tile_ownership_sums_to_full_frame(oracle):
     assert np.array_equal(acc.view(np.uint32), f.view(np.uint32))
 
 
-def test_nan_nee_ray_is_a_cheap_miss(oracle):
+@pytest.mark.parametrize("schedule", SCHEDULES)
+def test_nan_nee_ray_is_a_cheap_miss(oracle, schedule):
     """RandomFloat == 1.0 at the environment-NEE draw -> NaN shadow ray (util/random.hlsl:34-41).  The reference walks
     the whole tree for it; the kernels return the certain miss at once.  Frame identical to the faithful oracle,
     counters identical to the oracle's counting variant."""
     s = scenes.sponza_atrium(tex_size=4, detail=0.15)
-    pt = PathTracer(s, width=8, height=8, samplesPerPass=1)
+    pt = PathTracer(s, width=8, height=8, samplesPerPass=1, schedule=schedule)
     pt.set_stats_level(1)
     p = pt.params(seed=0xED3B3E)
     pt.render_pass(p)

@@ -54,6 +54,11 @@ struct PTContext {
     std::vector<EventPair> pending;             // recorded, not yet read
     std::vector<EventPair> freeEvents;
     PTTimings timings = {};
+    // schedule 1 (wavefront) state
+    PTWfBuffers wf = {};
+    void* wfArena = nullptr;
+    size_t wfArenaBytes = 0;
+    uint32_t* hostAlive = nullptr;              // pinned
 };
 
 namespace {
@@ -81,6 +86,37 @@ int ensure_frames(PTContext* c, uint32_t w, uint32_t h)
     }
     c->frameW = w; c->frameH = h;
     c->cur = 0;                         // PrepareRenderTexture re-created the targets -> Reset() (PathTracer.cs:211-215)
+    return PT_OK;
+}
+
+// one arena for all slot-indexed arrays of the wavefront schedule; re-carved when the slot count changes
+int ensure_wavefront(PTContext* c, uint32_t numSlots, uint32_t maxIterations)
+{
+    if (c->wf.flags && c->wf.numSlots == numSlots && c->wf.maxIterations >= maxIterations) return PT_OK;
+    const size_t n = numSlots;
+    const uint32_t numRows = 4u * (numSlots >> 6);
+    auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t total = align(n * 4) * 2 + align(n * 16) * 12 + align(n * 2) + align((size_t)maxIterations * 4) + align((size_t)numRows * 16 * 8);
+    if (c->wfArena && c->wfArenaBytes < total) { hipFree(c->wfArena); c->wfArena = nullptr; c->wfArenaBytes = 0; }
+    if (!c->wfArena) {
+        HIP_TRY(hipMalloc(&c->wfArena, total));
+        c->wfArenaBytes = total;
+    }
+    if (!c->hostAlive) HIP_TRY(hipHostMalloc((void**)&c->hostAlive, 64, hipHostMallocDefault));
+    char* p = (char*)c->wfArena;
+    auto carve = [&](size_t bytes) { char* q = p; p += align(bytes); return q; };
+    PTWfBuffers& B = c->wf;
+    B.flags = (uint32_t*)carve(n * 4);
+    B.rng = (uint32_t*)carve(n * 4);
+    float4** arrs[12] = {&B.ro, &B.rd, &B.rad, &B.thr, &B.color, &B.neeO, &B.envD, &B.lightD, &B.envC, &B.lightC, &B.pthr, &B.hit};
+    for (auto a : arrs) *a = (float4*)carve(n * 16);
+    B.occl = (uint8_t*)carve(n * 2);
+    B.aliveFlags = (uint32_t*)carve((size_t)maxIterations * 4);
+    B.statRows = (unsigned long long*)carve((size_t)numRows * 16 * 8);
+    B.numSlots = numSlots;
+    B.numStatRows = numRows;
+    B.maxIterations = maxIterations;
+    HIP_TRY(hipMemsetAsync(B.statRows, 0, (size_t)numRows * 16 * 8, c->stream));
     return PT_OK;
 }
 
@@ -141,6 +177,16 @@ int render_to(PTContext* c, const PTFrameParams* p, float4* dOut, const float4* 
     if (c->profiling) HIP_TRY(hipEventRecord(ep.start, c->stream));
     uint32_t launches = 0;
     switch (c->schedule) {
+    case 1: {
+        const uint32_t spp = p->SamplesPerPass > 1 ? (uint32_t)p->SamplesPerPass : 1u;
+        const uint32_t bounces = p->MaxRayBounces > 1u ? p->MaxRayBounces : 1u;
+        if (spp > 4095u || bounces > 8191u) return fail(PT_ERR_UNSUPPORTED, "schedule 1 packs SamplesPerPass <= 4095 and MaxRayBounces <= 8191");
+        // iterations: (bounces + 2) per sample when nothing is skipped; alpha-skips add iterations without adding depth
+        const uint64_t maxIt = (uint64_t)spp * (bounces + 3u) * 4u + 256u;
+        if ((rc = ensure_wavefront(c, pt_wf_num_slots(tm), (uint32_t)(maxIt > (1u << 24) ? (1u << 24) : maxIt)))) return rc;
+        HIP_TRY(pt_launch_wavefront(c->scene, *p, dAcc, dOut, tm, c->wf, c->dStats, c->statsLevel > 0, c->hostAlive, c->stream, &launches));
+        break;
+    }
     case 0:
     default:
         HIP_TRY(pt_launch_megakernel(c->scene, *p, dAcc, dOut, tm, c->dStats, c->statsLevel > 0, c->stream));
@@ -189,6 +235,8 @@ PT_API int PTDestroy(PTContext* c)
     for (auto* b : {&c->nodes, &c->tris, &c->attrs, &c->materials, &c->lights, &c->tex}) if (b->ptr) hipFree(b->ptr);
     for (int i = 0; i < 2; i++) if (c->frames[i]) hipFree(c->frames[i]);
     if (c->dStats) hipFree(c->dStats);
+    if (c->wfArena) hipFree(c->wfArena);
+    if (c->hostAlive) hipHostFree(c->hostAlive);
     for (auto& ep : c->pending) { hipEventDestroy(ep.start); hipEventDestroy(ep.stop); }
     for (auto& ep : c->freeEvents) { hipEventDestroy(ep.start); hipEventDestroy(ep.stop); }
     hipStreamDestroy(c->stream);
@@ -342,7 +390,7 @@ PT_API int PTResetTimings(PTContext* c)
 PT_API int PTSetSchedule(PTContext* c, int schedule)
 {
     if (!c) return fail(PT_ERR_INVALID_ARG, "ctx == NULL");
-    if (schedule != 0) return fail(PT_ERR_UNSUPPORTED, "unknown schedule");
+    if (schedule != 0 && schedule != 1) return fail(PT_ERR_UNSUPPORTED, "unknown schedule (0 = megakernel, 1 = wavefront)");
     c->schedule = schedule;
     return PT_OK;
 }

@@ -931,3 +931,194 @@ PT_DEV void generate_camera_ray(const PTFrameParams& P, uint32_t pixelX, uint32_
         direction = normalize3(focalPoint - origin);
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// One iteration of the per-pixel program, shared by every schedule.
+//
+// The reference's PathTrace loop (util/pathtrace.hlsl:10-131) + the sample loop of the kernel entry
+// (PathTracer.compute:66-98), cut at the traversal calls: a path alternates between "rays are being traced"
+// and path_step(), which (1) adds the NEE of the bounce shaded last time (now that its shadow rays are
+// resolved), (2) shades the closest hit that came back -- sky / light / material, NEE preparation, BSDF
+// sampling, throughput, Russian roulette -- and (3) when the sample ended, folds it into the pixel and
+// either starts the next sample (new camera ray) or writes the pixel.  Between two calls the schedule traces
+// up to three rays: env shadow (if hasPending && env.valid), light shadow (if hasPending && light.valid) and
+// the next closest-hit ray (if state == PS_TRACE).  Every float and every RNG draw happens in the reference's
+// order, whatever the schedule.
+// ------------------------------------------------------------------------------------------
+enum : uint32_t { PS_TRACE = 0u, PS_ENDING = 1u, PS_DONE = 2u };
+
+struct PathRegs {
+    v3 ro, rd;                   // the closest-hit ray in flight (state == PS_TRACE)
+    v3 radiance, throughput, color;
+    float scatterPdf, maxRoughness;
+    uint32_t rng, depth, state, sampleIdx;
+    NeeRay env, light;           // pending NEE of the last shaded bounce
+    v3 neeOrigin, pendThroughput;
+    bool hasPending, green;
+};
+
+PT_DEV void path_start_sample(const PTFrameParams& P, uint32_t pixelX, uint32_t pixelY, PathRegs& r, Counters& cn)
+{
+    cn.paths++;
+    r.radiance = mk3(0.0f);
+    r.throughput = mk3(1.0f);
+    r.depth = 0u;
+    r.scatterPdf = 0.0f;
+    r.maxRoughness = 0.0f;
+    generate_camera_ray(P, pixelX, pixelY, r.rng, r.ro, r.rd);
+    r.state = PS_TRACE;
+}
+
+PT_DEV void path_init(const PTFrameParams& P, uint32_t pixelX, uint32_t pixelY, uint32_t pixelIndex, PathRegs& r, Counters& cn)
+{
+    r.rng = pixelIndex * (P.CurrentSample + 1u) + P.RngSeedRoot;         // PathTracer.compute:60
+    r.sampleIdx = 0u;
+    r.color = mk3(0.0f);
+    r.env.valid = 0u; r.light.valid = 0u;
+    r.env.dir = mk3(0.0f); r.light.dir = mk3(0.0f);
+    r.env.contribution = mk3(0.0f); r.light.contribution = mk3(0.0f);
+    r.neeOrigin = mk3(0.0f); r.pendThroughput = mk3(0.0f);
+    r.hasPending = false; r.green = false;
+    path_start_sample(P, pixelX, pixelY, r, cn);
+}
+
+template <bool STATS>
+PT_DEV void path_step(const DScene& S, const PTFrameParams& P, PathRegs& r, const TraceHit& ch, bool occEnv, bool occLight,
+                      uint32_t pixelX, uint32_t pixelY, uint32_t pixelIndex,
+                      const float4* __restrict__ accumulated, float4* __restrict__ output, Counters& cn)
+{
+    // ---- (1) radiance += DirectLight(...) * throughput      (util/pathtrace.hlsl:93, deferred until the shadow rays are in)
+    if (r.hasPending) {
+        v3 Ld = mk3(0.0f);
+        if (r.env.valid == 1u && !occEnv) Ld = Ld + r.env.contribution;
+        if (r.light.valid == 1u && !occLight) Ld = Ld + r.light.contribution;
+        r.radiance = r.radiance + Ld * r.pendThroughput;
+        if (r.green) r.radiance = mk3(0.0f, 1.0f, 0.0f);      // NaN BSDF sample (util/pathtrace.hlsl:100-104)
+        r.hasPending = false;
+        r.green = false;
+    }
+
+    // ---- (2) shade the closest hit                           (util/pathtrace.hlsl:27-127)
+    if (r.state == PS_TRACE) {
+        const uint32_t maxRayBounces = P.MaxRayBounces > 1u ? P.MaxRayBounces : 1u;
+        SurfHit hit;
+        hit.distance = PT_FAR_PLANE;
+        hit.isLight = 0u;
+        hit.triIndex = 0u;
+        hit.materialIndex = 0;
+        hit.position = mk3(0.0f); hit.normal = mk3(0.0f); hit.ffnormal = mk3(0.0f);
+        hit.uv = {0.0f, 0.0f};
+        if (ch.t < PT_FAR_PLANE) fetch_hit_attributes<STATS>(S, r.ro, r.rd, ch, hit, cn);
+        intersect_lights<STATS>(S, r.ro, r.rd, hit, cn);
+
+        if (!(hit.distance < PT_FAR_PLANE)) {
+            v4 sky = sample_sky_radiance(P, r.rd, r.depth);
+            float misWeight = 1.0f;
+            if (r.depth > 0u) misWeight = power_heuristic(r.scatterPdf, sky.w);
+            if (misWeight > 0.0f) r.radiance = r.radiance + misWeight * mk3(sky.x, sky.y, sky.z) * r.throughput;
+            r.state = PS_ENDING;
+        } else if (S.hasLights && hit.isLight) {
+            DLight light = load_light(S, (int)hit.triIndex);
+            if (STATS) cn.lightFetches++;
+            r.radiance = r.radiance + light.emission * r.throughput;
+            r.state = PS_ENDING;
+        } else {
+            Material material = get_material<STATS>(S, hit.materialIndex, r.rd, hit, cn);
+            r.maxRoughness = pt_max(r.maxRoughness, material.roughness);
+            material.roughness = r.maxRoughness;
+            r.radiance = r.radiance + material.emission * r.throughput;
+            if (r.depth >= maxRayBounces) {
+                r.state = PS_ENDING;
+            } else {
+                v3 scatterL;
+                bool skip = false;
+                if (material.alphaMode == (float)PT_ALPHA_MODE_MASK && material.opacity < material.alphaCutoff) skip = true;
+                else if (material.alphaMode == (float)PT_ALPHA_MODE_BLEND && rnd(r.rng) > material.opacity) skip = true;
+                bool advance = true;
+                if (skip) {
+                    scatterL = r.rd;                             // rayDepth-- then ++: depth unchanged (util/pathtrace.hlsl:85-88)
+                } else {
+                    r.neeOrigin = nee_scatter_pos(hit);
+                    nee_prepare_environment(P, r.rd, hit, material, r.rng, r.env);
+                    nee_prepare_light<STATS>(S, r.rd, hit, material, r.neeOrigin, r.rng, r.light, cn);
+                    r.pendThroughput = r.throughput;
+                    r.hasPending = true;
+                    float pdf;
+                    v3 f = sample_brdf(material, -r.rd, hit.ffnormal, scatterL, pdf, r.rng);
+                    r.scatterPdf = pdf;
+                    if (pt_isnan(f.x) || pt_isnan(f.y) || pt_isnan(f.z)) {
+                        r.green = true;
+                        r.state = PS_ENDING;
+                        advance = false;
+                    } else if (pdf > 0.0f) {
+                        r.throughput = r.throughput * (f / pdf);
+                    } else {
+                        r.state = PS_ENDING;
+                        advance = false;
+                    }
+                    if (advance) r.depth++;
+                }
+                if (advance) {
+                    r.rd = scatterL;
+                    r.ro = hit.position + r.rd * PT_EPSILON;
+                    if (P.UseRussianRoulette) {
+                        float rrPcont = pt_min(pt_max(r.throughput.x, pt_max(r.throughput.y, r.throughput.z)) + 0.001f, 0.95f);
+                        if (rnd(r.rng) >= rrPcont) r.state = PS_ENDING;
+                        else r.throughput = r.throughput / rrPcont;
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- (3) end of a sample                                 (PathTracer.compute:77-98)
+    if (r.state == PS_ENDING && !r.hasPending) {
+        if (P.UseFireflyFilter) {
+            float lum = luminance3(r.radiance);
+            if (lum > P.MaxFireflyLuminance) r.radiance = r.radiance * (P.MaxFireflyLuminance / lum);
+        }
+        r.color = r.color + r.radiance;
+        r.sampleIdx++;
+        const uint32_t numSamples = P.SamplesPerPass > 1 ? (uint32_t)P.SamplesPerPass : 1u;
+        if (r.sampleIdx < numSamples) {
+            path_start_sample(P, pixelX, pixelY, r, cn);
+        } else {
+            const float fSamples = (float)numSamples;
+            float4 o4;
+            if (P.CurrentSample > 0u) {                           // PathTracer.compute:89-94
+                float4 a = accumulated[pixelIndex];
+                cn.pixelsRead++;
+                float cs = (float)P.CurrentSample;
+                v3 acc = (r.color + mk3(a.x, a.y, a.z) * cs) / (cs + fSamples);
+                o4 = make_float4(acc.x, acc.y, acc.z, 1.0f);
+            } else {
+                v3 acc = r.color / fSamples;
+                o4 = make_float4(acc.x, acc.y, acc.z, 1.0f);
+            }
+            output[pixelIndex] = o4;
+            cn.pixelsWritten++;
+            r.state = PS_DONE;
+        }
+    }
+}
+
+// Wave-level helpers (wave64).
+PT_DEV uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+PT_DEV uint32_t wave_max_u32(uint32_t v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
+    return v;
+}
+#define PT_NUM_COUNTERS 14
+PT_DEV void counters_to_array(const Counters& cn, uint32_t* vals)
+{
+    vals[0] = cn.paths; vals[1] = cn.closestRays; vals[2] = cn.shadowRays; vals[3] = cn.nodeVisits; vals[4] = cn.triTests;
+    vals[5] = cn.attrFetches; vals[6] = cn.materialFetches; vals[7] = cn.lightFetches; vals[8] = cn.texelFetches;
+    vals[9] = cn.texDescFetches; vals[10] = cn.pixelsWritten; vals[11] = cn.pixelsRead; vals[12] = cn.maxStack; vals[13] = cn.overflows;
+}

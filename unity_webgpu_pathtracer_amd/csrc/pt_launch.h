@@ -13,3 +13,23 @@ struct PTTileMap {
 
 hipError_t pt_launch_megakernel(const DScene& S, const PTFrameParams& P, const float4* accumulated, float4* output,
                                 const PTTileMap& tm, unsigned long long* gstats, bool fullStats, hipStream_t stream);
+
+// ---- schedule 1 (wavefront): slot-indexed path state in HBM (see pt_wavefront.hip) ----
+struct PTWfBuffers {
+    uint32_t* flags;            // [numSlots] packed state word
+    uint32_t* rng;              // [numSlots]
+    float4 *ro, *rd;            // closest-hit ray in flight: (origin, scatterPdf), (direction, maxRoughness)
+    float4 *rad, *thr, *color;  // radiance, throughput, per-pixel sample sum
+    float4 *neeO, *envD, *lightD;        // NEE shadow rays of the last shaded bounce
+    float4 *envC, *lightC, *pthr;        // their contributions and the throughput they apply to
+    float4* hit;                // [numSlots] (t, u, v, triIndex bits) written by trace kind 0
+    uint8_t* occl;              // [2][numSlots] written by trace kinds 1, 2
+    uint32_t* aliveFlags;       // [maxIterations]
+    unsigned long long* statRows;   // [numStatRows][16]
+    uint32_t numSlots, numStatRows, maxIterations;
+};
+
+uint32_t pt_wf_num_slots(const PTTileMap& tm);
+hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const float4* accumulated, float4* output,
+                               const PTTileMap& tm, const PTWfBuffers& B, unsigned long long* gstats, bool fullStats,
+                               uint32_t* hostAlive, hipStream_t stream, uint32_t* launchesOut);

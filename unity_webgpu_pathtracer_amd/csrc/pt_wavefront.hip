@@ -1,0 +1,267 @@
+// pt_wavefront.hip — schedule 1: the same per-pixel program as the megakernel, cut at the traversal calls.
+//
+// Why: in one fused kernel the Disney-BSDF shading code sets the register budget (185 VGPRs -> 2 waves/SIMD, or
+// 128 with spills -> 4), and lanes that shade wait for lanes that traverse and vice versa (measured VALU lane
+// utilisation well under 40 %).  Here every pixel owns a SLOT of path state in HBM and a pass is a sequence of
+//     trace  : one lane per (slot, ray kind) -- lean CWBVH traversal only, high occupancy
+//     shade  : one lane per slot -- path_step() of pt_device.h: apply NEE, shade, roulette, next sample / write pixel
+// repeated until every pixel has finished its SamplesPerPass samples.  Samples of a pixel stay sequential (one RNG
+// chain per pixel per pass, PathTracer.compute:60,66), so a slot carries exactly one path at a time and the number
+// of iterations is about SamplesPerPass x (bounces + 1).
+//
+// There are NO queues and NO global atomics: rays are found by scanning the slot-indexed flag words (a ray of
+// kind k exists for slot s iff the flags say so), results go to slot-indexed arrays, and termination is a plain
+// store of "somebody is still alive" per iteration that the host polls every few iterations.  Work counters are
+// accumulated in per-wave rows (plain read-modify-write: one wave owns a row) and folded once per pass.
+// Every fp32 value and RNG draw is produced by the same device functions in the same per-path order as in
+// schedule 0, so frames and counters are bit-identical between the two schedules and to the oracle.
+#include "pt_device.h"
+#include "pt_launch.h"
+
+namespace {
+
+// flags word: [1:0] state | [2] hasPending | [4:3] env.valid | [5] light.valid | [6] green | [18:7] sampleIdx | [31:19] depth
+PT_DEV uint32_t pack_flags(const PathRegs& r)
+{
+    return (r.state & 3u) | ((r.hasPending ? 1u : 0u) << 2) | ((r.env.valid & 3u) << 3) | ((r.light.valid & 1u) << 5) |
+           ((r.green ? 1u : 0u) << 6) | ((r.sampleIdx & 0xFFFu) << 7) | ((r.depth & 0x1FFFu) << 19);
+}
+PT_DEV uint32_t fl_state(uint32_t f) { return f & 3u; }
+PT_DEV bool fl_pending(uint32_t f) { return (f >> 2) & 1u; }
+PT_DEV uint32_t fl_env(uint32_t f) { return (f >> 3) & 3u; }
+PT_DEV uint32_t fl_light(uint32_t f) { return (f >> 5) & 1u; }
+
+// slot -> pixel: the megakernel's mapping (16x16 blocks, one wave per 8x8 tile, interleaved block ownership)
+PT_DEV bool slot_to_pixel(const PTTileMap& tm, uint32_t slot, uint32_t& px, uint32_t& py)
+{
+    const uint32_t bpr = (tm.blocksX + tm.world - 1u) / tm.world;       // owned blocks per block-row (upper bound)
+    const uint32_t block = slot >> 8, tid = slot & 255u;
+    const uint32_t by = block / bpr, k = block % bpr;
+    const uint32_t first = (uint32_t)(((int)tm.rank - (int)(by % tm.world) + (int)tm.world) % (int)tm.world);
+    const uint32_t bx = first + k * tm.world;
+    const uint32_t wave = tid >> 6, lane = tid & 63u;
+    px = bx * 16u + (wave & 1u) * 8u + (lane & 7u);
+    py = by * 16u + (wave >> 1) * 8u + (lane >> 3);
+    return bx < tm.blocksX && by < tm.blocksY && px < tm.coverW && py < tm.coverH;
+}
+
+PT_DEV float4 f4(v3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
+PT_DEV v3 xyz(float4 v) { return mk3(v.x, v.y, v.z); }
+
+PT_DEV void store_path(const PTWfBuffers& B, uint32_t slot, const PathRegs& r, bool writeNee)
+{
+    B.flags[slot] = pack_flags(r);
+    B.rng[slot] = r.rng;
+    B.ro[slot] = f4(r.ro, r.scatterPdf);
+    B.rd[slot] = f4(r.rd, r.maxRoughness);
+    B.rad[slot] = f4(r.radiance, 0.0f);
+    B.thr[slot] = f4(r.throughput, 0.0f);
+    B.color[slot] = f4(r.color, 0.0f);
+    if (writeNee) {
+        B.neeO[slot] = f4(r.neeOrigin, 0.0f);
+        B.envD[slot] = f4(r.env.dir, 0.0f);
+        B.lightD[slot] = f4(r.light.dir, 0.0f);
+        B.envC[slot] = f4(r.env.contribution, 0.0f);
+        B.lightC[slot] = f4(r.light.contribution, 0.0f);
+        B.pthr[slot] = f4(r.pendThroughput, 0.0f);
+    }
+}
+
+// per-wave counter rows: one wave owns a row, so a plain read-modify-write is race-free across launches of one stream
+template <bool STATS>
+PT_DEV void flush_counters(const Counters& cn, unsigned long long* rows, uint32_t row, uint32_t lane)
+{
+    uint32_t vals[PT_NUM_COUNTERS];
+    counters_to_array(cn, vals);
+    unsigned long long* p = rows + (size_t)row * 16u;
+#pragma unroll
+    for (int i = 0; i < PT_NUM_COUNTERS; ++i) {
+        if (!STATS && (i >= 3 && i <= 9)) continue;
+        if (!STATS && i >= 12) continue;
+        if (i == 12) {
+            uint32_t m = wave_max_u32(vals[i]);
+            if (lane == 0 && m > p[i]) p[i] = m;
+        } else {
+            uint32_t s = wave_sum_u32(vals[i]);
+            if (lane == 0 && s) p[i] += s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// init: every owned pixel starts its first sample (camera ray in the slot, state = TRACE)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pt_wf_init(PTFrameParams P, PTTileMap tm, PTWfBuffers B)
+{
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    if (slot >= B.numSlots) return;
+    uint32_t px, py;
+    Counters cn = {};
+    if (!slot_to_pixel(tm, slot, px, py)) { B.flags[slot] = PS_DONE; return; }
+    PathRegs r;
+    path_init(P, px, py, py * P.OutputWidth + px, r, cn);
+    store_path(B, slot, r, false);
+    flush_counters<false>(cn, B.statRows, blockIdx.x * 4u + (threadIdx.x >> 6), threadIdx.x & 63u);
+}
+
+// ------------------------------------------------------------------------------------------
+// trace: one lane per (slot, kind).  kind 0 = closest hit of the bounce ray, 1 = environment NEE, 2 = light NEE
+// ------------------------------------------------------------------------------------------
+#ifndef PT_WF_TRACE_MIN_WAVES
+#define PT_WF_TRACE_MIN_WAVES 6
+#endif
+#ifndef PT_WF_LDS_STACK
+#define PT_WF_LDS_STACK 8
+#endif
+
+template <bool STATS>
+__global__ __launch_bounds__(256, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace(DScene S, PTWfBuffers B)
+{
+    __shared__ uint2 s_stack[PT_LDS_STACK][256];
+    const uint32_t nb = B.numSlots >> 8;
+    const uint32_t kind = blockIdx.x / nb;
+    const uint32_t slot = (blockIdx.x % nb) * 256u + threadIdx.x;
+    const uint32_t f = B.flags[slot];
+    bool valid;
+    if (kind == 0u) valid = fl_state(f) == PS_TRACE;
+    else if (kind == 1u) valid = fl_pending(f) && fl_env(f) != 0u;
+    else valid = fl_pending(f) && fl_light(f) != 0u;
+    Counters cn = {};
+    if (valid) {
+        v3 o, d;
+        if (kind == 0u) { o = xyz(B.ro[slot]); d = xyz(B.rd[slot]); }
+        else { o = xyz(B.neeO[slot]); d = xyz(kind == 1u ? B.envD[slot] : B.lightD[slot]); }
+        TravStack st;
+        st.lds = &s_stack[0][threadIdx.x];
+        st.stride = 256u;
+        TraceHit h;
+        h.t = PT_FAR_PLANE; h.u = 0.0f; h.v = 0.0f; h.triIndex = 0u;
+        traverse_cwbvh<STATS>(S, o, d, kind != 0u, h, st, cn);
+        if (kind == 0u) { B.hit[slot] = make_float4(h.t, h.u, h.v, pt_asfloat(h.triIndex)); cn.closestRays++; }
+        else { B.occl[(size_t)(kind - 1u) * B.numSlots + slot] = h.t < PT_FAR_PLANE ? 1 : 0; cn.shadowRays++; }
+    }
+    flush_counters<STATS>(cn, B.statRows, (B.numSlots >> 6) + blockIdx.x * 4u + (threadIdx.x >> 6), threadIdx.x & 63u);
+}
+
+// ------------------------------------------------------------------------------------------
+// shade: one lane per slot
+// ------------------------------------------------------------------------------------------
+#ifndef PT_WF_SHADE_MIN_WAVES
+#define PT_WF_SHADE_MIN_WAVES 3
+#endif
+
+template <bool STATS>
+__global__ __launch_bounds__(256, PT_WF_SHADE_MIN_WAVES) void pt_wf_shade(DScene S, PTFrameParams P, PTTileMap tm, PTWfBuffers B,
+                                                                         const float4* __restrict__ accumulated,
+                                                                         float4* __restrict__ output, uint32_t iteration)
+{
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t f = B.flags[slot];
+    Counters cn = {};
+    bool alive = false;
+    if (fl_state(f) != PS_DONE) {
+        uint32_t px, py;
+        slot_to_pixel(tm, slot, px, py);
+        PathRegs r;
+        r.state = fl_state(f);
+        r.hasPending = fl_pending(f);
+        r.env.valid = fl_env(f);
+        r.light.valid = fl_light(f);
+        r.green = (f >> 6) & 1u;
+        r.sampleIdx = (f >> 7) & 0xFFFu;
+        r.depth = f >> 19;
+        r.rng = B.rng[slot];
+        float4 q;
+        q = B.ro[slot]; r.ro = xyz(q); r.scatterPdf = q.w;
+        q = B.rd[slot]; r.rd = xyz(q); r.maxRoughness = q.w;
+        r.radiance = xyz(B.rad[slot]);
+        r.throughput = xyz(B.thr[slot]);
+        r.color = xyz(B.color[slot]);
+        r.env.dir = mk3(0.0f); r.light.dir = mk3(0.0f); r.neeOrigin = mk3(0.0f);
+        r.env.contribution = mk3(0.0f); r.light.contribution = mk3(0.0f); r.pendThroughput = mk3(0.0f);
+        bool occEnv = false, occLight = false;
+        if (r.hasPending) {
+            r.env.contribution = xyz(B.envC[slot]);
+            r.light.contribution = xyz(B.lightC[slot]);
+            r.pendThroughput = xyz(B.pthr[slot]);
+            occEnv = B.occl[slot] != 0;
+            occLight = B.occl[(size_t)B.numSlots + slot] != 0;
+        }
+        TraceHit ch;
+        ch.t = PT_FAR_PLANE; ch.u = 0.0f; ch.v = 0.0f; ch.triIndex = 0u;
+        if (r.state == PS_TRACE) {
+            float4 h = B.hit[slot];
+            ch.t = h.x; ch.u = h.y; ch.v = h.z; ch.triIndex = pt_asuint(h.w);
+        }
+        path_step<STATS>(S, P, r, ch, occEnv, occLight, px, py, py * P.OutputWidth + px, accumulated, output, cn);
+        store_path(B, slot, r, r.hasPending);
+        alive = r.state != PS_DONE;
+    }
+    if (__any(alive) && (threadIdx.x & 63u) == 0u) B.aliveFlags[iteration] = 1u;     // plain store; polled by the host
+    flush_counters<STATS>(cn, B.statRows, blockIdx.x * 4u + (threadIdx.x >> 6), threadIdx.x & 63u);
+}
+
+// fold the per-wave rows into the context's 14 counters (PTStats order) and clear them
+__global__ __launch_bounds__(256) void pt_wf_fold_rows(unsigned long long* rows, uint32_t numRows, unsigned long long* gstats)
+{
+    unsigned long long acc[PT_NUM_COUNTERS] = {};
+    for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < numRows; r += gridDim.x * 256u) {
+        unsigned long long* p = rows + (size_t)r * 16u;
+#pragma unroll
+        for (int i = 0; i < PT_NUM_COUNTERS; ++i) {
+            unsigned long long v = p[i];
+            if (i == 12) acc[i] = v > acc[i] ? v : acc[i]; else acc[i] += v;
+            p[i] = 0ull;
+        }
+    }
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (int i = 0; i < PT_NUM_COUNTERS; ++i) {
+        unsigned long long v = acc[i];
+        for (int off = 32; off > 0; off >>= 1) {
+            unsigned long long o = __shfl_xor(v, off, 64);
+            if (i == 12) v = o > v ? o : v; else v += o;
+        }
+        if (lane == 0 && v) { if (i == 12) atomicMax(&gstats[i], v); else atomicAdd(&gstats[i], v); }
+    }
+}
+
+} // namespace
+
+uint32_t pt_wf_num_slots(const PTTileMap& tm)
+{
+    const uint32_t bpr = (tm.blocksX + tm.world - 1u) / tm.world;
+    return bpr * tm.blocksY * 256u;
+}
+
+hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const float4* accumulated, float4* output,
+                               const PTTileMap& tm, const PTWfBuffers& B, unsigned long long* gstats, bool fullStats,
+                               uint32_t* hostAlive, hipStream_t stream, uint32_t* launchesOut)
+{
+    const uint32_t nb = B.numSlots >> 8;
+    uint32_t launches = 0;
+    hipError_t e;
+    if ((e = hipMemsetAsync(B.aliveFlags, 0, sizeof(uint32_t) * B.maxIterations, stream)) != hipSuccess) return e;
+    hipLaunchKernelGGL(pt_wf_init, dim3(nb), dim3(256), 0, stream, P, tm, B);
+    launches++;
+    const uint32_t spp = P.SamplesPerPass > 1 ? (uint32_t)P.SamplesPerPass : 1u;
+    const uint32_t firstCheck = spp * 2u;        // no pixel can finish before `spp` iterations; most need far more
+    uint32_t it = 0;
+    for (;; ++it) {
+        if (it >= B.maxIterations) return hipErrorLaunchFailure;     // bounded: never spin forever
+        if (fullStats) hipLaunchKernelGGL(pt_wf_trace<true>, dim3(nb * 3u), dim3(256), 0, stream, S, B);
+        else hipLaunchKernelGGL(pt_wf_trace<false>, dim3(nb * 3u), dim3(256), 0, stream, S, B);
+        if (fullStats) hipLaunchKernelGGL(pt_wf_shade<true>, dim3(nb), dim3(256), 0, stream, S, P, tm, B, accumulated, output, it);
+        else hipLaunchKernelGGL(pt_wf_shade<false>, dim3(nb), dim3(256), 0, stream, S, P, tm, B, accumulated, output, it);
+        launches += 2;
+        if (it >= firstCheck && ((it - firstCheck) & 3u) == 0u) {
+            if ((e = hipMemcpyAsync(hostAlive, B.aliveFlags + it, sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+            if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+            if (*hostAlive == 0u) break;
+        }
+    }
+    hipLaunchKernelGGL(pt_wf_fold_rows, dim3(256), dim3(256), 0, stream, B.statRows, B.numStatRows, gstats);
+    launches++;
+    if (launchesOut) *launchesOut = launches;
+    return hipGetLastError();
+}

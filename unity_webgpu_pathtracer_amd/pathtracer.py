@@ -57,7 +57,7 @@ class PathTracer:
     def __init__(self, scene: Scene, device: int = 0, width: int = 256, height: int = 256,
                  samplesPerPass: int = 1, maxSamples: int = 100000, maxRayBounces: int = 4,
                  useRussianRoulette: bool = True, fireflyFilter: bool = False, maxFireflyLuminance: float = 10.0,
-                 rank: int = 0, world_size: int = 1, reference_dispatch: bool = False):
+                 rank: int = 0, world_size: int = 1, reference_dispatch: bool = False, schedule: int = None):
         self.lib = plugin.load_library()
         self.scene = scene
         self.width, self.height = width, height
@@ -78,6 +78,8 @@ class PathTracer:
         if world_size > 1:
             plugin.check(self.lib.PTSetTileOwnership(self.ctx, rank, world_size))
         self.rank, self.world_size = rank, world_size
+        if schedule is not None:
+            self.set_schedule(schedule)
 
     # ---- PathTracer.cs:318-322
     def Reset(self):

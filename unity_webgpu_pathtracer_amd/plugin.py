@@ -17,7 +17,7 @@ from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libunity-webgpu-pathtracer-plugin.so"      # Plugin/CMakeLists.txt:3 / TinyBVH.cs:8-12
-LIB_PATH = os.path.join(_HERE, "lib", LIB_NAME)
+LIB_PATH = os.environ.get("PT_PLUGIN") or os.path.join(_HERE, "lib", LIB_NAME)   # PT_PLUGIN: explicit build to load
 
 _lib = None
 
