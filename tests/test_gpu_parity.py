@@ -42,7 +42,7 @@ ALL_COUNTERS = ["paths", "closestHitRays", "shadowRays", "nodeVisits", "triTests
                 "stackOverflows"]
 
 
-SCHEDULES = [0, 1]          # 0 = megakernel, 1 = wavefront (csrc/pt_wavefront.hip); both must be bit-identical to the oracle
+SCHEDULES = [0, 1, 2]       # 0 = megakernel, 1 = wavefront + refill trace, 2 = wavefront, one ray per lane: all bit-identical to the oracle
 
 
 @pytest.mark.parametrize("schedule", SCHEDULES)

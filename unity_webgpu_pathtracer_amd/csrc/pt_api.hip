@@ -177,14 +177,15 @@ int render_to(PTContext* c, const PTFrameParams* p, float4* dOut, const float4* 
     if (c->profiling) HIP_TRY(hipEventRecord(ep.start, c->stream));
     uint32_t launches = 0;
     switch (c->schedule) {
-    case 1: {
+    case 1:
+    case 2: {
         const uint32_t spp = p->SamplesPerPass > 1 ? (uint32_t)p->SamplesPerPass : 1u;
         const uint32_t bounces = p->MaxRayBounces > 1u ? p->MaxRayBounces : 1u;
         if (spp > 4095u || bounces > 8191u) return fail(PT_ERR_UNSUPPORTED, "schedule 1 packs SamplesPerPass <= 4095 and MaxRayBounces <= 8191");
         // iterations: (bounces + 2) per sample when nothing is skipped; alpha-skips add iterations without adding depth
         const uint64_t maxIt = (uint64_t)spp * (bounces + 3u) * 4u + 256u;
         if ((rc = ensure_wavefront(c, pt_wf_num_slots(tm), (uint32_t)(maxIt > (1u << 24) ? (1u << 24) : maxIt)))) return rc;
-        HIP_TRY(pt_launch_wavefront(c->scene, *p, dAcc, dOut, tm, c->wf, c->dStats, c->statsLevel > 0, c->hostAlive, c->stream, &launches));
+        HIP_TRY(pt_launch_wavefront(c->scene, *p, dAcc, dOut, tm, c->wf, c->dStats, c->statsLevel > 0, c->hostAlive, c->stream, &launches, c->schedule == 1 ? 0 : 1));
         break;
     }
     case 0:
@@ -390,7 +391,7 @@ PT_API int PTResetTimings(PTContext* c)
 PT_API int PTSetSchedule(PTContext* c, int schedule)
 {
     if (!c) return fail(PT_ERR_INVALID_ARG, "ctx == NULL");
-    if (schedule != 0 && schedule != 1) return fail(PT_ERR_UNSUPPORTED, "unknown schedule (0 = megakernel, 1 = wavefront)");
+    if (schedule < 0 || schedule > 2) return fail(PT_ERR_UNSUPPORTED, "unknown schedule (0 = megakernel, 1 = wavefront with refill trace, 2 = wavefront, one ray per lane)");
     c->schedule = schedule;
     return PT_OK;
 }

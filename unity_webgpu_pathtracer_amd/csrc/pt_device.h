@@ -1122,3 +1122,80 @@ PT_DEV void counters_to_array(const Counters& cn, uint32_t* vals)
     vals[5] = cn.attrFetches; vals[6] = cn.materialFetches; vals[7] = cn.lightFetches; vals[8] = cn.texelFetches;
     vals[9] = cn.texDescFetches; vals[10] = cn.pixelsWritten; vals[11] = cn.pixelsRead; vals[12] = cn.maxStack; vals[13] = cn.overflows;
 }
+
+// ------------------------------------------------------------------------------------------
+// Resumable CWBVH traversal: the loop of traverse_cwbvh cut into steps, so that a wave can retire finished rays
+// and pull new ones into the idle lanes between steps (pt_wavefront.hip, refill trace kernel).  One call of
+// ray_step() is exactly one iteration of the reference's outer while(true) (util/bvh.hlsl:141-197):
+// [node step | adopt triangle group] -> all triangles of the group -> [pop | finish]; the per-ray operation order,
+// hence t/u/v/triIndex and the node/triangle counters, are those of traverse_cwbvh.
+// ------------------------------------------------------------------------------------------
+struct RayState {
+    v3 o, d, invDir;
+    uint32_t octinv4;
+    uint2 ng, tg;
+    uint32_t sp;
+    TraceHit hit;
+    bool anyHit, overflow;
+};
+
+// returns true when the ray is finished before it started (NaN ray: certain miss, see traverse_cwbvh)
+PT_DEV bool ray_begin(RayState& r, v3 o, v3 d, bool anyHit)
+{
+    r.o = o; r.d = d; r.anyHit = anyHit; r.overflow = false;
+    r.hit.t = PT_FAR_PLANE; r.hit.u = 0.0f; r.hit.v = 0.0f; r.hit.triIndex = 0u;
+    r.sp = 0u;
+    r.ng = make_uint2(0u, 0x80000000u);
+    r.tg = make_uint2(0u, 0u);
+    r.invDir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    r.octinv4 = (7u - ((d.x < 0.0f ? 4u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 1u : 0u))) * 0x1010101u;
+    return pt_isnan(o.x) || pt_isnan(o.y) || pt_isnan(o.z) || pt_isnan(d.x) || pt_isnan(d.y) || pt_isnan(d.z);
+}
+
+// one outer iteration; returns true when the traversal is complete
+template <bool STATS>
+PT_DEV bool ray_step(const DScene& S, RayState& r, TravStack& st, Counters& cn)
+{
+    if (r.ng.y > 0x00FFFFFFu) {
+        uint32_t mask = r.ng.y;
+        uint32_t childBitIndex = 31u - (uint32_t)__clz((int)mask);
+        uint32_t childNodeBaseIndex = r.ng.x;
+        r.ng.y &= ~(1u << childBitIndex);
+        if (r.ng.y > 0x00FFFFFFu) {
+            stack_push(st, r.sp, r.ng);
+            if (r.sp >= PT_BVH_STACK_SIZE) r.overflow = true;
+            r.sp++;
+            if (STATS) cn.maxStack = r.sp > cn.maxStack ? r.sp : cn.maxStack;
+        }
+        uint32_t slotIndex = (childBitIndex - 24u) ^ (r.octinv4 & 255u);
+        uint32_t relativeIndex = (uint32_t)__popc(mask & ~(0xFFFFFFFFu << slotIndex));
+        uint32_t childNodeIndex = childNodeBaseIndex + relativeIndex;
+        const uint4* np = S.nodes + (size_t)childNodeIndex * 5;
+        uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+        uint32_t hitmask = cwbvh_node_hitmask(r.o, r.invDir, r.octinv4, r.hit.t, n0, n1, n2, n3, n4);
+        if (STATS) cn.nodeVisits++;
+        r.ng.x = n1.x;
+        r.ng.y = (hitmask & 0xFF000000u) | (n0.w >> 24);
+        r.tg.x = n1.y;
+        r.tg.y = hitmask & 0x00FFFFFFu;
+    } else {
+        r.tg = r.ng;
+        r.ng = make_uint2(0u, 0u);
+    }
+    while (r.tg.y != 0u) {
+        uint32_t triangleIndex = 31u - (uint32_t)__clz((int)r.tg.y);
+        uint32_t triAddr = r.tg.x + triangleIndex * 3u;
+        intersect_triangle(S.tris, triAddr, r.o, r.d, r.hit);
+        if (STATS) cn.triTests++;
+        r.tg.y -= 1u << triangleIndex;
+        if (r.anyHit && r.hit.t < PT_FAR_PLANE) { r.tg.y = 0u; r.ng.y = 0u; r.sp = 0u; }
+    }
+    if (r.ng.y <= 0x00FFFFFFu) {
+        if (r.sp > 0u) { --r.sp; r.ng = stack_pop(st, r.sp); }
+        else {
+            if (STATS && r.overflow) cn.overflows++;
+            return true;
+        }
+    }
+    return false;
+}

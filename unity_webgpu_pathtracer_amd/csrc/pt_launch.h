@@ -32,4 +32,4 @@ struct PTWfBuffers {
 uint32_t pt_wf_num_slots(const PTTileMap& tm);
 hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const float4* accumulated, float4* output,
                                const PTTileMap& tm, const PTWfBuffers& B, unsigned long long* gstats, bool fullStats,
-                               uint32_t* hostAlive, hipStream_t stream, uint32_t* launchesOut);
+                               uint32_t* hostAlive, hipStream_t stream, uint32_t* launchesOut, int traceVariant);

@@ -144,6 +144,108 @@ __global__ __launch_bounds__(256, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace(DScene
 }
 
 // ------------------------------------------------------------------------------------------
+// trace with refill (schedule 1): persistent-threads ray scheduling inside each wave, no atomics.
+//
+// A wave owns PT_WF_RANGE consecutive slots = 3 * PT_WF_RANGE potential rays, enumerated kind-major (all bounce
+// rays of the range, then the environment shadow rays, then the light shadow rays: neighbours in the enumeration are
+// neighbours on screen and of one kind, i.e. as coherent as this path tracer gets).  The wave keeps 64 resumable
+// traversals in flight; whenever PT_WF_REFILL or more lanes have retired their ray it scans the next 64 candidates
+// (one coalesced read of the flag words), ballots which exist, and compacts them into the idle lanes through a
+// 64-entry LDS exchange (rank-of-set-bit on both masks).  Rays of very different length therefore never hold a wave
+// hostage, and the enumeration order -- hence every result -- is independent of timing.
+// ------------------------------------------------------------------------------------------
+#ifndef PT_WF_RANGE
+#define PT_WF_RANGE 256u        // slots per wave (power of two)
+#endif
+#ifndef PT_WF_REFILL
+#define PT_WF_REFILL 16u        // refill when at least this many lanes are idle
+#endif
+
+PT_DEV bool ray_exists(uint32_t f, uint32_t kind)
+{
+    if (kind == 0u) return fl_state(f) == PS_TRACE;
+    if (kind == 1u) return fl_pending(f) && fl_env(f) != 0u;
+    return fl_pending(f) && fl_light(f) != 0u;
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(256, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(DScene S, PTWfBuffers B)
+{
+    __shared__ uint2 s_stack[PT_LDS_STACK][256];
+    __shared__ uint32_t s_xchg[4][64];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint32_t gw = blockIdx.x * 4u + wave;
+    const uint32_t slotBase = gw * PT_WF_RANGE;
+    if (slotBase >= B.numSlots) return;                              // wave-uniform
+    const uint32_t nItems = 3u * PT_WF_RANGE;
+    const unsigned long long ltMask = (1ull << lane) - 1ull;
+    volatile uint32_t* xchg = s_xchg[wave];
+
+    Counters cn = {};
+    TravStack st;
+    st.lds = &s_stack[0][tid];
+    st.stride = 256u;
+    RayState rs;
+    rs.sp = 0u; rs.anyHit = false; rs.overflow = false;
+    bool have = false;
+    uint32_t mySlot = 0u, myKind = 0u;
+    uint32_t cursor = 0u;
+
+    while (true) {
+        uint32_t nIdle = (uint32_t)__popcll(__ballot(!have));
+        // ---- refill: compact the next existing rays of this wave's range into the idle lanes
+        while (cursor < nItems && (nIdle >= PT_WF_REFILL || nIdle == 64u)) {
+            const unsigned long long idle = __ballot(!have);
+            const uint32_t item = cursor + lane;
+            const uint32_t kind = item / PT_WF_RANGE;
+            const uint32_t slot = slotBase + (item & (PT_WF_RANGE - 1u));
+            bool valid = item < nItems && slot < B.numSlots;
+            if (valid) valid = ray_exists(B.flags[slot], kind);
+            const unsigned long long V = __ballot(valid);
+            const uint32_t nV = (uint32_t)__popcll(V);
+            const uint32_t take = nIdle < nV ? nIdle : nV;
+            const uint32_t rankV = (uint32_t)__popcll(V & ltMask);
+            uint32_t consumed = 64u;
+            if (take < nV) consumed = (uint32_t)__ffsll((long long)__ballot(valid && rankV == take)) - 1u;   // first ray NOT taken
+            if (valid && rankV < take) xchg[rankV] = item;
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t rankI = (uint32_t)__popcll(idle & ltMask);
+            if (!have && rankI < take) {
+                const uint32_t it = xchg[rankI];
+                myKind = it / PT_WF_RANGE;
+                mySlot = slotBase + (it & (PT_WF_RANGE - 1u));
+                v3 o, d;
+                if (myKind == 0u) { o = xyz(B.ro[mySlot]); d = xyz(B.rd[mySlot]); }
+                else { o = xyz(B.neeO[mySlot]); d = xyz(myKind == 1u ? B.envD[mySlot] : B.lightD[mySlot]); }
+                if (myKind == 0u) cn.closestRays++; else cn.shadowRays++;
+                if (ray_begin(rs, o, d, myKind != 0u)) {
+                    // NaN ray: certain miss
+                    if (myKind == 0u) B.hit[mySlot] = make_float4(PT_FAR_PLANE, 0.0f, 0.0f, 0.0f);
+                    else B.occl[(size_t)(myKind - 1u) * B.numSlots + mySlot] = 0;
+                } else have = true;
+            }
+            __builtin_amdgcn_wave_barrier();
+            cursor += consumed;
+            nIdle = (uint32_t)__popcll(__ballot(!have));
+        }
+        if (nIdle == 64u) break;                                      // range exhausted and nothing in flight
+        // ---- traverse until enough lanes have retired (or, once the range is exhausted, until all have)
+        const uint32_t stopAt = cursor < nItems ? PT_WF_REFILL : 64u;
+        do {
+            if (have) {
+                if (ray_step<STATS>(S, rs, st, cn)) {
+                    if (myKind == 0u) B.hit[mySlot] = make_float4(rs.hit.t, rs.hit.u, rs.hit.v, pt_asfloat(rs.hit.triIndex));
+                    else B.occl[(size_t)(myKind - 1u) * B.numSlots + mySlot] = rs.hit.t < PT_FAR_PLANE ? 1 : 0;
+                    have = false;
+                }
+            }
+            nIdle = (uint32_t)__popcll(__ballot(!have));
+        } while (nIdle < stopAt);
+    }
+    flush_counters<STATS>(cn, B.statRows, (B.numSlots >> 6) + gw, lane);
+}
+
+// ------------------------------------------------------------------------------------------
 // shade: one lane per slot
 // ------------------------------------------------------------------------------------------
 #ifndef PT_WF_SHADE_MIN_WAVES
@@ -236,8 +338,9 @@ uint32_t pt_wf_num_slots(const PTTileMap& tm)
 
 hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const float4* accumulated, float4* output,
                                const PTTileMap& tm, const PTWfBuffers& B, unsigned long long* gstats, bool fullStats,
-                               uint32_t* hostAlive, hipStream_t stream, uint32_t* launchesOut)
+                               uint32_t* hostAlive, hipStream_t stream, uint32_t* launchesOut, int traceVariant)
 {
+    const uint32_t refillBlocks = (B.numSlots + PT_WF_RANGE * 4u - 1u) / (PT_WF_RANGE * 4u);
     const uint32_t nb = B.numSlots >> 8;
     uint32_t launches = 0;
     hipError_t e;
@@ -249,8 +352,13 @@ hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const fl
     uint32_t it = 0;
     for (;; ++it) {
         if (it >= B.maxIterations) return hipErrorLaunchFailure;     // bounded: never spin forever
-        if (fullStats) hipLaunchKernelGGL(pt_wf_trace<true>, dim3(nb * 3u), dim3(256), 0, stream, S, B);
-        else hipLaunchKernelGGL(pt_wf_trace<false>, dim3(nb * 3u), dim3(256), 0, stream, S, B);
+        if (traceVariant == 0) {
+            if (fullStats) hipLaunchKernelGGL(pt_wf_trace_refill<true>, dim3(refillBlocks), dim3(256), 0, stream, S, B);
+            else hipLaunchKernelGGL(pt_wf_trace_refill<false>, dim3(refillBlocks), dim3(256), 0, stream, S, B);
+        } else {
+            if (fullStats) hipLaunchKernelGGL(pt_wf_trace<true>, dim3(nb * 3u), dim3(256), 0, stream, S, B);
+            else hipLaunchKernelGGL(pt_wf_trace<false>, dim3(nb * 3u), dim3(256), 0, stream, S, B);
+        }
         if (fullStats) hipLaunchKernelGGL(pt_wf_shade<true>, dim3(nb), dim3(256), 0, stream, S, P, tm, B, accumulated, output, it);
         else hipLaunchKernelGGL(pt_wf_shade<false>, dim3(nb), dim3(256), 0, stream, S, P, tm, B, accumulated, output, it);
         launches += 2;
