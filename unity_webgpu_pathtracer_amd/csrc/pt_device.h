@@ -108,21 +108,26 @@ PT_DEV float rnd(uint32_t& s) { return pt_random_float(&s); }
 #endif
 #define PT_SPILL_STACK (PT_BVH_STACK_SIZE - PT_LDS_STACK)
 
-struct TravStack {
+template <int LDSN>
+struct TravStackT {
+    static constexpr uint32_t kLds = LDSN;
     uint2* lds;                 // &smem[0][threadIdx.x]; entry stride = blockDim.x
     uint32_t stride;
-    uint2 spill[PT_SPILL_STACK];
+    uint2 spill[PT_BVH_STACK_SIZE - LDSN];
 };
+typedef TravStackT<PT_LDS_STACK> TravStack;
 
-PT_DEV void stack_push(TravStack& st, uint32_t sp, uint2 v)
+template <class ST>
+PT_DEV void stack_push(ST& st, uint32_t sp, uint2 v)
 {
-    if (sp < PT_LDS_STACK) st.lds[sp * st.stride] = v;
-    else if (sp < PT_BVH_STACK_SIZE) st.spill[sp - PT_LDS_STACK] = v;
+    if (sp < ST::kLds) st.lds[sp * st.stride] = v;
+    else if (sp < PT_BVH_STACK_SIZE) st.spill[sp - ST::kLds] = v;
 }
-PT_DEV uint2 stack_pop(TravStack& st, uint32_t sp)
+template <class ST>
+PT_DEV uint2 stack_pop(ST& st, uint32_t sp)
 {
-    if (sp < PT_LDS_STACK) return st.lds[sp * st.stride];
-    if (sp < PT_BVH_STACK_SIZE) return st.spill[sp - PT_LDS_STACK];
+    if (sp < ST::kLds) return st.lds[sp * st.stride];
+    if (sp < PT_BVH_STACK_SIZE) return st.spill[sp - ST::kLds];
     return make_uint2(0u, 0u);
 }
 
@@ -185,7 +190,10 @@ struct TraceHit {
 // util/bvh.hlsl:23-59
 PT_DEV void intersect_triangle(const float4* __restrict__ tris, uint32_t triAddr, v3 o, v3 d, TraceHit& hit)
 {
+    // all 48 bytes are requested before the first use, so the whole test costs ONE memory round trip
+    // (left to itself hipcc sinks the v0 load under the determinant test: two dependent round trips)
     float4 t0 = tris[triAddr + 0], t1 = tris[triAddr + 1], t2 = tris[triAddr + 2];
+    asm volatile("" : "+v"(t0.x), "+v"(t1.x), "+v"(t2.x), "+v"(t2.w));
     v3 e2 = mk3(t0.x, t0.y, t0.z), e1 = mk3(t1.x, t1.y, t1.z), v0 = mk3(t2.x, t2.y, t2.z);
     v3 r = cross3(d, e2);
     float a = dot3(e1, r);
@@ -218,8 +226,8 @@ PT_DEV void intersect_triangle(const float4* __restrict__ tris, uint32_t triAddr
 // RandomCosineHemisphere return the zero vector and normalize() turn it into NaN (util/random.hlsl:34-41,
 // util/light.hlsl:141) -- about two NEE rays per 1080p/8spp frame.  One lane visiting 45k nodes + 250k
 // triangles stalls its whole kernel for ~80 ms, so the miss is returned immediately (same result).
-template <bool STATS>
-PT_DEV void traverse_cwbvh(const DScene& S, v3 o, v3 d, bool anyHit, TraceHit& hit, TravStack& st, Counters& cn)
+template <bool STATS, class ST>
+PT_DEV void traverse_cwbvh(const DScene& S, v3 o, v3 d, bool anyHit, TraceHit& hit, ST& st, Counters& cn)
 {
     if (pt_isnan(o.x) || pt_isnan(o.y) || pt_isnan(o.z) || pt_isnan(d.x) || pt_isnan(d.y) || pt_isnan(d.z)) return;
     v3 invDir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -1153,8 +1161,8 @@ PT_DEV bool ray_begin(RayState& r, v3 o, v3 d, bool anyHit)
 }
 
 // one outer iteration; returns true when the traversal is complete
-template <bool STATS>
-PT_DEV bool ray_step(const DScene& S, RayState& r, TravStack& st, Counters& cn)
+template <bool STATS, class ST>
+PT_DEV bool ray_step(const DScene& S, RayState& r, ST& st, Counters& cn)
 {
     if (r.ng.y > 0x00FFFFFFu) {
         uint32_t mask = r.ng.y;

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void pt_wf_init(PTFrameParams P, PTTileMap tm,
 // trace: one lane per (slot, kind).  kind 0 = closest hit of the bounce ray, 1 = environment NEE, 2 = light NEE
 // ------------------------------------------------------------------------------------------
 #ifndef PT_WF_TRACE_MIN_WAVES
-#define PT_WF_TRACE_MIN_WAVES 6
+#define PT_WF_TRACE_MIN_WAVES 8
 #endif
 #ifndef PT_WF_LDS_STACK
 #define PT_WF_LDS_STACK 8
@@ -155,10 +155,13 @@ __global__ __launch_bounds__(256, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace(DScene
 // hostage, and the enumeration order -- hence every result -- is independent of timing.
 // ------------------------------------------------------------------------------------------
 #ifndef PT_WF_RANGE
-#define PT_WF_RANGE 256u        // slots per wave (power of two)
+#define PT_WF_RANGE 64u         // slots per wave (power of two); small ranges balance load across CUs (measured 64 > 128 > 256)
 #endif
 #ifndef PT_WF_REFILL
 #define PT_WF_REFILL 16u        // refill when at least this many lanes are idle
+#endif
+#ifndef PT_WF_TRACE_BLOCK
+#define PT_WF_TRACE_BLOCK 64u   // threads per workgroup of the refill trace kernel (one wave: a finished wave frees its slot at once)
 #endif
 
 PT_DEV bool ray_exists(uint32_t f, uint32_t kind)
@@ -169,12 +172,12 @@ PT_DEV bool ray_exists(uint32_t f, uint32_t kind)
 }
 
 template <bool STATS>
-__global__ __launch_bounds__(256, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(DScene S, PTWfBuffers B)
+__global__ __launch_bounds__(PT_WF_TRACE_BLOCK, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(DScene S, PTWfBuffers B)
 {
-    __shared__ uint2 s_stack[PT_LDS_STACK][256];
-    __shared__ uint32_t s_xchg[4][64];
+    __shared__ uint2 s_stack[PT_WF_LDS_STACK][PT_WF_TRACE_BLOCK];
+    __shared__ uint32_t s_xchg[PT_WF_TRACE_BLOCK / 64u][64];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-    const uint32_t gw = blockIdx.x * 4u + wave;
+    const uint32_t gw = blockIdx.x * (PT_WF_TRACE_BLOCK / 64u) + wave;
     const uint32_t slotBase = gw * PT_WF_RANGE;
     if (slotBase >= B.numSlots) return;                              // wave-uniform
     const uint32_t nItems = 3u * PT_WF_RANGE;
@@ -182,9 +185,9 @@ __global__ __launch_bounds__(256, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill
     volatile uint32_t* xchg = s_xchg[wave];
 
     Counters cn = {};
-    TravStack st;
+    TravStackT<PT_WF_LDS_STACK> st;
     st.lds = &s_stack[0][tid];
-    st.stride = 256u;
+    st.stride = PT_WF_TRACE_BLOCK;
     RayState rs;
     rs.sp = 0u; rs.anyHit = false; rs.overflow = false;
     bool have = false;
@@ -340,7 +343,8 @@ hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const fl
                                const PTTileMap& tm, const PTWfBuffers& B, unsigned long long* gstats, bool fullStats,
                                uint32_t* hostAlive, hipStream_t stream, uint32_t* launchesOut, int traceVariant)
 {
-    const uint32_t refillBlocks = (B.numSlots + PT_WF_RANGE * 4u - 1u) / (PT_WF_RANGE * 4u);
+    const uint32_t slotsPerBlock = PT_WF_RANGE * (PT_WF_TRACE_BLOCK / 64u);
+    const uint32_t refillBlocks = (B.numSlots + slotsPerBlock - 1u) / slotsPerBlock;
     const uint32_t nb = B.numSlots >> 8;
     uint32_t launches = 0;
     hipError_t e;
@@ -353,8 +357,8 @@ hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const fl
     for (;; ++it) {
         if (it >= B.maxIterations) return hipErrorLaunchFailure;     // bounded: never spin forever
         if (traceVariant == 0) {
-            if (fullStats) hipLaunchKernelGGL(pt_wf_trace_refill<true>, dim3(refillBlocks), dim3(256), 0, stream, S, B);
-            else hipLaunchKernelGGL(pt_wf_trace_refill<false>, dim3(refillBlocks), dim3(256), 0, stream, S, B);
+            if (fullStats) hipLaunchKernelGGL(pt_wf_trace_refill<true>, dim3(refillBlocks), dim3(PT_WF_TRACE_BLOCK), 0, stream, S, B);
+            else hipLaunchKernelGGL(pt_wf_trace_refill<false>, dim3(refillBlocks), dim3(PT_WF_TRACE_BLOCK), 0, stream, S, B);
         } else {
             if (fullStats) hipLaunchKernelGGL(pt_wf_trace<true>, dim3(nb * 3u), dim3(256), 0, stream, S, B);
             else hipLaunchKernelGGL(pt_wf_trace<false>, dim3(nb * 3u), dim3(256), 0, stream, S, B);
