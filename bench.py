@@ -232,9 +232,12 @@ def main():
                        "sharding": "interleaved 16x16 blocks, one RCCL reduce per frame" if distributed else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                         "kernel": "pt_megakernel" if args.schedule == 0 else f"schedule{args.schedule}",
+                         "kernel": {0: "pt_megakernel", 1: "pt_wf_trace_refill + pt_wf_shade (whole pass)", 2: "pt_wf_trace + pt_wf_shade (whole pass)",
+                                    3: "pt_wf_trace_persist + pt_wf_shade (whole pass)"}[args.schedule],
                          "kernel_ms": round(main_res["kernel_ms"], 4),
                          "algorithmic_bytes_per_launch": round(main_res["alg_bytes_per_launch"]),
+                         "counters_per_launch": {k: round(v) for k, v in main_res["counters_per_launch"].items()},
+                         "max_stack_depth": main_res["max_stack_depth"],
                          "note": "rank-0 kernel; working set is Infinity-Cache resident, the path is latency/divergence-bound (DESIGN.md)"},
         }
     if not args.no_extra and not distributed:

@@ -96,7 +96,7 @@ int ensure_wavefront(PTContext* c, uint32_t numSlots, uint32_t maxIterations)
     const size_t n = numSlots;
     const uint32_t numRows = 4u * (numSlots >> 6);
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    size_t total = align(n * 4) * 2 + align(n * 16) * 12 + align(n * 2) + align((size_t)maxIterations * 4) + align((size_t)numRows * 16 * 8);
+    size_t total = align(n * 4) * 2 + align(n * 16) * 12 + align(n * 2) + align((size_t)maxIterations * 4) + align((size_t)numRows * 16 * 8) + align(8 * 32 * 4);
     if (c->wfArena && c->wfArenaBytes < total) { hipFree(c->wfArena); c->wfArena = nullptr; c->wfArenaBytes = 0; }
     if (!c->wfArena) {
         HIP_TRY(hipMalloc(&c->wfArena, total));
@@ -113,6 +113,12 @@ int ensure_wavefront(PTContext* c, uint32_t numSlots, uint32_t maxIterations)
     B.occl = (uint8_t*)carve(n * 2);
     B.aliveFlags = (uint32_t*)carve((size_t)maxIterations * 4);
     B.statRows = (unsigned long long*)carve((size_t)numRows * 16 * 8);
+    B.chunkHeads = (uint32_t*)carve(8 * 32 * 4);
+    {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+        B.residentWaves = (uint32_t)prop.multiProcessorCount * 4u * 8u;
+    }
     B.numSlots = numSlots;
     B.numStatRows = numRows;
     B.maxIterations = maxIterations;
@@ -178,14 +184,15 @@ int render_to(PTContext* c, const PTFrameParams* p, float4* dOut, const float4* 
     uint32_t launches = 0;
     switch (c->schedule) {
     case 1:
-    case 2: {
+    case 2:
+    case 3: {
         const uint32_t spp = p->SamplesPerPass > 1 ? (uint32_t)p->SamplesPerPass : 1u;
         const uint32_t bounces = p->MaxRayBounces > 1u ? p->MaxRayBounces : 1u;
         if (spp > 4095u || bounces > 8191u) return fail(PT_ERR_UNSUPPORTED, "schedule 1 packs SamplesPerPass <= 4095 and MaxRayBounces <= 8191");
         // iterations: (bounces + 2) per sample when nothing is skipped; alpha-skips add iterations without adding depth
         const uint64_t maxIt = (uint64_t)spp * (bounces + 3u) * 4u + 256u;
         if ((rc = ensure_wavefront(c, pt_wf_num_slots(tm), (uint32_t)(maxIt > (1u << 24) ? (1u << 24) : maxIt)))) return rc;
-        HIP_TRY(pt_launch_wavefront(c->scene, *p, dAcc, dOut, tm, c->wf, c->dStats, c->statsLevel > 0, c->hostAlive, c->stream, &launches, c->schedule == 1 ? 0 : 1));
+        HIP_TRY(pt_launch_wavefront(c->scene, *p, dAcc, dOut, tm, c->wf, c->dStats, c->statsLevel > 0, c->hostAlive, c->stream, &launches, c->schedule == 1 ? 2 : (c->schedule == 2 ? 1 : 0)));
         break;
     }
     case 0:
@@ -391,7 +398,8 @@ PT_API int PTResetTimings(PTContext* c)
 PT_API int PTSetSchedule(PTContext* c, int schedule)
 {
     if (!c) return fail(PT_ERR_INVALID_ARG, "ctx == NULL");
-    if (schedule < 0 || schedule > 2) return fail(PT_ERR_UNSUPPORTED, "unknown schedule (0 = megakernel, 1 = wavefront with refill trace, 2 = wavefront, one ray per lane)");
+    if (schedule < 0 || schedule > 3)
+        return fail(PT_ERR_UNSUPPORTED, "unknown schedule (0 = megakernel, 1 = wavefront + refill trace, 2 = wavefront, one ray per lane, 3 = wavefront + persistent dynamic-chunk trace)");
     c->schedule = schedule;
     return PT_OK;
 }

@@ -25,8 +25,10 @@ struct PTWfBuffers {
     float4* hit;                // [numSlots] (t, u, v, triIndex bits) written by trace kind 0
     uint8_t* occl;              // [2][numSlots] written by trace kinds 1, 2
     uint32_t* aliveFlags;       // [maxIterations]
+    uint32_t* chunkHeads;       // [8 shards x 32 words]: work counters of the persistent trace kernel, one 128-B line each
     unsigned long long* statRows;   // [numStatRows][16]
     uint32_t numSlots, numStatRows, maxIterations;
+    uint32_t residentWaves;     // waves the device holds at the trace kernel's occupancy (CUs x 4 SIMDs x 8)
 };
 
 uint32_t pt_wf_num_slots(const PTTileMap& tm);

@@ -20,6 +20,9 @@
 
 namespace {
 
+#define PT_WF_CHUNK 64u         // slots per work chunk of the persistent trace kernel (= one scan window per ray kind)
+#define PT_WF_SHARDS 8u         // chunk counters, one per XCD
+
 // flags word: [1:0] state | [2] hasPending | [4:3] env.valid | [5] light.valid | [6] green | [18:7] sampleIdx | [31:19] depth
 PT_DEV uint32_t pack_flags(const PathRegs& r)
 {
@@ -94,6 +97,7 @@ PT_DEV void flush_counters(const Counters& cn, unsigned long long* rows, uint32_
 __global__ __launch_bounds__(256) void pt_wf_init(PTFrameParams P, PTTileMap tm, PTWfBuffers B)
 {
     const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    if (blockIdx.x == 0u && threadIdx.x < PT_WF_SHARDS) B.chunkHeads[threadIdx.x * 32u] = 0u;
     if (slot >= B.numSlots) return;
     uint32_t px, py;
     Counters cn = {};
@@ -249,6 +253,114 @@ __global__ __launch_bounds__(PT_WF_TRACE_BLOCK, PT_WF_TRACE_MIN_WAVES) void pt_w
 }
 
 // ------------------------------------------------------------------------------------------
+// persistent trace (schedule 1): the refill kernel above, made persistent.  The grid is exactly the number of
+// waves the chip holds; a wave that has scanned its 64-slot chunk pulls the NEXT chunk index from a device counter
+// while its remaining rays are still in flight, so lanes are refilled continuously and nothing drains until the
+// very end of the launch.  Chunk counters are sharded 8 ways (one per XCD under round-robin workgroup placement,
+// blockIdx % 8) on separate 128-byte lines; a wave takes from its own shard first and steals from the others when
+// it runs dry: ~numSlots/64 returning atomics per launch in total, i.e. one per 192 candidate rays.
+// Which wave traces which ray depends on timing; what is computed for a ray does not.
+// ------------------------------------------------------------------------------------------
+PT_DEV bool next_chunk(uint32_t* heads, uint32_t numChunks, uint32_t shard, uint32_t& chunk)
+{
+    // lane 0 asks; everybody gets the answer.  Shard sh owns the chunks c with c % 8 == sh.
+    uint32_t result = 0xFFFFFFFFu;
+    if ((threadIdx.x & 63u) == 0u) {
+        for (uint32_t t = 0; t < PT_WF_SHARDS; ++t) {
+            const uint32_t sh = (shard + t) & (PT_WF_SHARDS - 1u);
+            const uint32_t inShard = (numChunks + PT_WF_SHARDS - 1u - sh) / PT_WF_SHARDS;
+            if (inShard == 0u) continue;
+            const uint32_t k = atomicAdd(&heads[sh * 32u], 1u);
+            if (k < inShard) { result = k * PT_WF_SHARDS + sh; break; }
+        }
+    }
+    result = __shfl(result, 0, 64);
+    chunk = result;
+    return result != 0xFFFFFFFFu;
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_persist(DScene S, PTWfBuffers B)
+{
+    __shared__ uint2 s_stack[PT_WF_LDS_STACK][64];
+    __shared__ uint32_t s_xchg[64];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t numChunks = (B.numSlots + PT_WF_CHUNK - 1u) / PT_WF_CHUNK;
+    const uint32_t shard = blockIdx.x & (PT_WF_SHARDS - 1u);
+    const uint32_t nItems = 3u * PT_WF_CHUNK;
+    const unsigned long long ltMask = (1ull << lane) - 1ull;
+    volatile uint32_t* xchg = s_xchg;
+
+    Counters cn = {};
+    TravStackT<PT_WF_LDS_STACK> st;
+    st.lds = &s_stack[0][lane];
+    st.stride = 64u;
+    RayState rs;
+    rs.sp = 0u; rs.anyHit = false; rs.overflow = false;
+    bool have = false;
+    uint32_t mySlot = 0u, myKind = 0u;
+    uint32_t cursor = nItems, slotBase = 0u;        // no chunk yet
+    bool more = true;                                // chunks may remain
+
+    while (true) {
+        uint32_t nIdle = (uint32_t)__popcll(__ballot(!have));
+        // ---- refill from the current chunk, pulling new chunks as needed
+        while (nIdle >= PT_WF_REFILL || nIdle == 64u) {
+            if (cursor >= nItems) {
+                uint32_t chunk;
+                if (!more || !next_chunk(B.chunkHeads, numChunks, shard, chunk)) { more = false; break; }
+                slotBase = chunk * PT_WF_CHUNK;
+                cursor = 0u;
+            }
+            const unsigned long long idle = __ballot(!have);
+            const uint32_t item = cursor + lane;
+            const uint32_t kind = item / PT_WF_CHUNK;
+            const uint32_t slot = slotBase + (item & (PT_WF_CHUNK - 1u));
+            bool valid = item < nItems && slot < B.numSlots;
+            if (valid) valid = ray_exists(B.flags[slot], kind);
+            const unsigned long long V = __ballot(valid);
+            const uint32_t nV = (uint32_t)__popcll(V);
+            const uint32_t take = nIdle < nV ? nIdle : nV;
+            const uint32_t rankV = (uint32_t)__popcll(V & ltMask);
+            uint32_t consumed = 64u;
+            if (take < nV) consumed = (uint32_t)__ffsll((long long)__ballot(valid && rankV == take)) - 1u;
+            if (valid && rankV < take) xchg[rankV] = item;
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t rankI = (uint32_t)__popcll(idle & ltMask);
+            if (!have && rankI < take) {
+                const uint32_t it = xchg[rankI];
+                myKind = it / PT_WF_CHUNK;
+                mySlot = slotBase + (it & (PT_WF_CHUNK - 1u));
+                v3 o, d;
+                if (myKind == 0u) { o = xyz(B.ro[mySlot]); d = xyz(B.rd[mySlot]); }
+                else { o = xyz(B.neeO[mySlot]); d = xyz(myKind == 1u ? B.envD[mySlot] : B.lightD[mySlot]); }
+                if (myKind == 0u) cn.closestRays++; else cn.shadowRays++;
+                if (ray_begin(rs, o, d, myKind != 0u)) {
+                    if (myKind == 0u) B.hit[mySlot] = make_float4(PT_FAR_PLANE, 0.0f, 0.0f, 0.0f);
+                    else B.occl[(size_t)(myKind - 1u) * B.numSlots + mySlot] = 0;
+                } else have = true;
+            }
+            __builtin_amdgcn_wave_barrier();
+            cursor += consumed;
+            nIdle = (uint32_t)__popcll(__ballot(!have));
+        }
+        if (nIdle == 64u) break;                                      // no chunk left and nothing in flight
+        const uint32_t stopAt = more ? PT_WF_REFILL : 64u;
+        do {
+            if (have) {
+                if (ray_step<STATS>(S, rs, st, cn)) {
+                    if (myKind == 0u) B.hit[mySlot] = make_float4(rs.hit.t, rs.hit.u, rs.hit.v, pt_asfloat(rs.hit.triIndex));
+                    else B.occl[(size_t)(myKind - 1u) * B.numSlots + mySlot] = rs.hit.t < PT_FAR_PLANE ? 1 : 0;
+                    have = false;
+                }
+            }
+            nIdle = (uint32_t)__popcll(__ballot(!have));
+        } while (nIdle < stopAt);
+    }
+    flush_counters<STATS>(cn, B.statRows, (B.numSlots >> 6) + blockIdx.x, lane);
+}
+
+// ------------------------------------------------------------------------------------------
 // shade: one lane per slot
 // ------------------------------------------------------------------------------------------
 #ifndef PT_WF_SHADE_MIN_WAVES
@@ -261,6 +373,7 @@ __global__ __launch_bounds__(256, PT_WF_SHADE_MIN_WAVES) void pt_wf_shade(DScene
                                                                          float4* __restrict__ output, uint32_t iteration)
 {
     const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    if (blockIdx.x == 0u && threadIdx.x < PT_WF_SHARDS) B.chunkHeads[threadIdx.x * 32u] = 0u;   // for the next trace launch
     const uint32_t f = B.flags[slot];
     Counters cn = {};
     bool alive = false;
@@ -357,6 +470,12 @@ hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const fl
     for (;; ++it) {
         if (it >= B.maxIterations) return hipErrorLaunchFailure;     // bounded: never spin forever
         if (traceVariant == 0) {
+            const uint32_t numChunks = (B.numSlots + PT_WF_CHUNK - 1u) / PT_WF_CHUNK;
+            uint32_t waves = B.residentWaves;
+            if (waves > numChunks) waves = numChunks;
+            if (fullStats) hipLaunchKernelGGL(pt_wf_trace_persist<true>, dim3(waves), dim3(64), 0, stream, S, B);
+            else hipLaunchKernelGGL(pt_wf_trace_persist<false>, dim3(waves), dim3(64), 0, stream, S, B);
+        } else if (traceVariant == 2) {
             if (fullStats) hipLaunchKernelGGL(pt_wf_trace_refill<true>, dim3(refillBlocks), dim3(PT_WF_TRACE_BLOCK), 0, stream, S, B);
             else hipLaunchKernelGGL(pt_wf_trace_refill<false>, dim3(refillBlocks), dim3(PT_WF_TRACE_BLOCK), 0, stream, S, B);
         } else {
