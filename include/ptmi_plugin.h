@@ -198,8 +198,11 @@ PT_API int PTSetProfiling(PTContext* ctx, int enabled);
 PT_API int PTGetTimings(PTContext* ctx, PTTimings* out);
 PT_API int PTResetTimings(PTContext* ctx);
 
-/* Select the kernel schedule: 0 = default, others are named in DESIGN.md.  All schedules
- * produce bit-identical frames. */
+/* Select the kernel schedule.  All schedules produce bit-identical frames and counters:
+ *   0  megakernel: one lane per pixel, one launch per pass
+ *   1  wavefront (default): slot-indexed path state, refill trace kernel + shade kernel, host-sync-free, passes overlap
+ *   2  wavefront with the plain one-ray-per-lane trace kernel
+ *   3  wavefront with the persistent dynamic-chunk trace kernel */
 PT_API int PTSetSchedule(PTContext* ctx, int schedule);
 
 /* Text of the last error on the calling thread ("" if none). */

@@ -7,6 +7,7 @@
 #include "pt_launch.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -48,17 +49,21 @@ struct PTContext {
     int cur = 0;
     int rank = 0, world = 1;
     int statsLevel = 0;
-    int schedule = 0;
+    int schedule = 1;                           // 0 megakernel, 1 wavefront + refill trace (default), 2, 3: see PTSetSchedule
     unsigned long long* dStats = nullptr;       // 14 counters, PTStats order
     bool profiling = false;
     std::vector<EventPair> pending;             // recorded, not yet read
     std::vector<EventPair> freeEvents;
     PTTimings timings = {};
-    // schedule 1 (wavefront) state
-    PTWfBuffers wf = {};
-    void* wfArena = nullptr;
-    size_t wfArenaBytes = 0;
-    uint32_t* hostAlive = nullptr;              // pinned
+    // wavefront schedules: PT_WF_SETS path-state sets, each with its own stream, so consecutive passes overlap
+    struct WfSet {
+        PTWfBuffers wf = {};
+        void* arena = nullptr;
+        size_t arenaBytes = 0;
+        hipStream_t stream = nullptr;
+        hipEvent_t callEv = nullptr, done = nullptr;
+    } sets[PT_WF_SETS];
+    uint32_t nextSet = 0;
 };
 
 namespace {
@@ -89,23 +94,29 @@ int ensure_frames(PTContext* c, uint32_t w, uint32_t h)
     return PT_OK;
 }
 
-// one arena for all slot-indexed arrays of the wavefront schedule; re-carved when the slot count changes
-int ensure_wavefront(PTContext* c, uint32_t numSlots, uint32_t maxIterations)
+// one arena for all slot-indexed arrays of a wavefront state set; re-carved when the slot count changes
+int ensure_wavefront(PTContext* c, PTContext::WfSet& set, uint32_t numSlots, uint32_t maxIterations)
 {
-    if (c->wf.flags && c->wf.numSlots == numSlots && c->wf.maxIterations >= maxIterations) return PT_OK;
+    if (!set.stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&set.stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&set.callEv, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&set.done, hipEventDisableTiming));
+    }
+    if (set.wf.flags && set.wf.numSlots == numSlots && set.wf.maxIterations >= maxIterations) return PT_OK;
+    HIP_TRY(hipStreamSynchronize(set.stream));
     const size_t n = numSlots;
     const uint32_t numRows = 4u * (numSlots >> 6);
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    size_t total = align(n * 4) * 2 + align(n * 16) * 12 + align(n * 2) + align((size_t)maxIterations * 4) + align((size_t)numRows * 16 * 8) + align(8 * 32 * 4);
-    if (c->wfArena && c->wfArenaBytes < total) { hipFree(c->wfArena); c->wfArena = nullptr; c->wfArenaBytes = 0; }
-    if (!c->wfArena) {
-        HIP_TRY(hipMalloc(&c->wfArena, total));
-        c->wfArenaBytes = total;
+    size_t total = align(n * 4) * 2 + align(n * 16) * 12 + align(n * 2) + align((size_t)maxIterations * 4) +
+                   align((size_t)numRows * 16 * 8) + align(8 * 32 * 4);
+    if (set.arena && set.arenaBytes < total) { hipFree(set.arena); set.arena = nullptr; set.arenaBytes = 0; }
+    if (!set.arena) {
+        HIP_TRY(hipMalloc(&set.arena, total));
+        set.arenaBytes = total;
     }
-    if (!c->hostAlive) HIP_TRY(hipHostMalloc((void**)&c->hostAlive, 64, hipHostMallocDefault));
-    char* p = (char*)c->wfArena;
+    char* p = (char*)set.arena;
     auto carve = [&](size_t bytes) { char* q = p; p += align(bytes); return q; };
-    PTWfBuffers& B = c->wf;
+    PTWfBuffers& B = set.wf;
     B.flags = (uint32_t*)carve(n * 4);
     B.rng = (uint32_t*)carve(n * 4);
     float4** arrs[12] = {&B.ro, &B.rd, &B.rad, &B.thr, &B.color, &B.neeO, &B.envD, &B.lightD, &B.envC, &B.lightC, &B.pthr, &B.hit};
@@ -122,7 +133,7 @@ int ensure_wavefront(PTContext* c, uint32_t numSlots, uint32_t maxIterations)
     B.numSlots = numSlots;
     B.numStatRows = numRows;
     B.maxIterations = maxIterations;
-    HIP_TRY(hipMemsetAsync(B.statRows, 0, (size_t)numRows * 16 * 8, c->stream));
+    HIP_TRY(hipMemsetAsync(B.statRows, 0, (size_t)numRows * 16 * 8, set.stream));
     return PT_OK;
 }
 
@@ -176,11 +187,6 @@ int render_to(PTContext* c, const PTFrameParams* p, float4* dOut, const float4* 
         if (!c->freeEvents.empty()) { ep = c->freeEvents.back(); c->freeEvents.pop_back(); }
         else { HIP_TRY(hipEventCreate(&ep.start)); HIP_TRY(hipEventCreate(&ep.stop)); }
     }
-    // pixels this context does not own must read as exact zeros (sum over ranks == single-GPU frame)
-    if (c->world > 1)
-        HIP_TRY(hipMemsetAsync(dOut, 0, (size_t)p->OutputWidth * p->OutputHeight * sizeof(float4), c->stream));
-
-    if (c->profiling) HIP_TRY(hipEventRecord(ep.start, c->stream));
     uint32_t launches = 0;
     switch (c->schedule) {
     case 1:
@@ -188,21 +194,34 @@ int render_to(PTContext* c, const PTFrameParams* p, float4* dOut, const float4* 
     case 3: {
         const uint32_t spp = p->SamplesPerPass > 1 ? (uint32_t)p->SamplesPerPass : 1u;
         const uint32_t bounces = p->MaxRayBounces > 1u ? p->MaxRayBounces : 1u;
-        if (spp > 4095u || bounces > 8191u) return fail(PT_ERR_UNSUPPORTED, "schedule 1 packs SamplesPerPass <= 4095 and MaxRayBounces <= 8191");
-        // iterations: (bounces + 2) per sample when nothing is skipped; alpha-skips add iterations without adding depth
-        const uint64_t maxIt = (uint64_t)spp * (bounces + 3u) * 4u + 256u;
-        if ((rc = ensure_wavefront(c, pt_wf_num_slots(tm), (uint32_t)(maxIt > (1u << 24) ? (1u << 24) : maxIt)))) return rc;
-        HIP_TRY(pt_launch_wavefront(c->scene, *p, dAcc, dOut, tm, c->wf, c->dStats, c->statsLevel > 0, c->hostAlive, c->stream, &launches, c->schedule == 1 ? 2 : (c->schedule == 2 ? 1 : 0)));
+        if (spp > 4095u || bounces > 8191u) return fail(PT_ERR_UNSUPPORTED, "wavefront schedules pack SamplesPerPass <= 4095 and MaxRayBounces <= 8191");
+        const uint64_t maxIt = (uint64_t)spp * (bounces + 2u) + 4u;
+        PTContext::WfSet& set = c->sets[c->nextSet];
+        c->nextSet = (c->nextSet + 1u) % PT_WF_SETS;
+        if ((rc = ensure_wavefront(c, set, pt_wf_num_slots(tm), (uint32_t)(maxIt > 65536u ? 65536u : maxIt)))) return rc;
+        // the launch chain runs on the set's own stream; only its resolve (which reads `accumulated` and writes `output`)
+        // is ordered after what the caller has enqueued on the context stream so far, the previous pass included
+        HIP_TRY(hipEventRecord(set.callEv, c->stream));
+        if (c->profiling) HIP_TRY(hipEventRecord(ep.start, set.stream));
+        HIP_TRY(pt_launch_wavefront(c->scene, *p, dAcc, dOut, tm, set.wf, c->dStats, c->statsLevel > 0, set.stream, set.callEv,
+                                    c->world > 1, &launches, c->schedule == 1 ? 2 : (c->schedule == 2 ? 1 : 0)));
+        if (c->profiling) HIP_TRY(hipEventRecord(ep.stop, set.stream));
+        HIP_TRY(hipEventRecord(set.done, set.stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream, set.done, 0));          // consumers of the context stream see the finished frame
         break;
     }
     case 0:
     default:
+        // pixels this context does not own must read as exact zeros (sum over ranks == single-GPU frame)
+        if (c->world > 1)
+            HIP_TRY(hipMemsetAsync(dOut, 0, (size_t)p->OutputWidth * p->OutputHeight * sizeof(float4), c->stream));
+        if (c->profiling) HIP_TRY(hipEventRecord(ep.start, c->stream));
         HIP_TRY(pt_launch_megakernel(c->scene, *p, dAcc, dOut, tm, c->dStats, c->statsLevel > 0, c->stream));
+        if (c->profiling) HIP_TRY(hipEventRecord(ep.stop, c->stream));
         launches = 1;
         break;
     }
     if (c->profiling) {
-        HIP_TRY(hipEventRecord(ep.stop, c->stream));
         ep.launches = launches;
         c->pending.push_back(ep);
     }
@@ -243,8 +262,12 @@ PT_API int PTDestroy(PTContext* c)
     for (auto* b : {&c->nodes, &c->tris, &c->attrs, &c->materials, &c->lights, &c->tex}) if (b->ptr) hipFree(b->ptr);
     for (int i = 0; i < 2; i++) if (c->frames[i]) hipFree(c->frames[i]);
     if (c->dStats) hipFree(c->dStats);
-    if (c->wfArena) hipFree(c->wfArena);
-    if (c->hostAlive) hipHostFree(c->hostAlive);
+    for (auto& set : c->sets) {
+        if (set.stream) { hipStreamSynchronize(set.stream); hipStreamDestroy(set.stream); }
+        if (set.arena) hipFree(set.arena);
+        if (set.callEv) hipEventDestroy(set.callEv);
+        if (set.done) hipEventDestroy(set.done);
+    }
     for (auto& ep : c->pending) { hipEventDestroy(ep.start); hipEventDestroy(ep.stop); }
     for (auto& ep : c->freeEvents) { hipEventDestroy(ep.start); hipEventDestroy(ep.stop); }
     hipStreamDestroy(c->stream);
@@ -263,6 +286,8 @@ PT_API int PTSetScene(PTContext* c, const PTSceneDesc* s)
     if ((s->features & PT_FEATURE_HAS_LIGHTS) && (!s->lights || s->lightCount == 0)) return fail(PT_ERR_INVALID_ARG, "HAS_LIGHTS without lights");
     if ((s->features & PT_FEATURE_HAS_TEXTURES) && (!s->textureData || s->textureDataUints == 0)) return fail(PT_ERR_INVALID_ARG, "HAS_TEXTURES without texture data");
     HIP_TRY(hipSetDevice(c->device));
+    for (auto& set : c->sets) if (set.stream) HIP_TRY(hipStreamSynchronize(set.stream));   // no pass may still read the old scene
+    HIP_TRY(hipStreamSynchronize(c->stream));
     int rc;
     if ((rc = upload(c, c->nodes, s->bvhNodes, s->bvhNodesBytes))) return rc;
     if ((rc = upload(c, c->tris, s->bvhTris, s->bvhTrisBytes))) return rc;

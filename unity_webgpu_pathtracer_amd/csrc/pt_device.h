@@ -990,7 +990,10 @@ PT_DEV void path_init(const PTFrameParams& P, uint32_t pixelX, uint32_t pixelY, 
     path_start_sample(P, pixelX, pixelY, r, cn);
 }
 
-template <bool STATS>
+// INLINE_RESOLVE: write the pixel (running mean with AccumulatedOutput) when its last sample ends, as the reference
+// kernel does.  Without it the pixel's sample sum stays in r.color and a separate resolve step applies the same formula
+// later (pt_wavefront.hip), which lets consecutive passes overlap.
+template <bool STATS, bool INLINE_RESOLVE = true>
 PT_DEV void path_step(const DScene& S, const PTFrameParams& P, PathRegs& r, const TraceHit& ch, bool occEnv, bool occLight,
                       uint32_t pixelX, uint32_t pixelY, uint32_t pixelIndex,
                       const float4* __restrict__ accumulated, float4* __restrict__ output, Counters& cn)
@@ -1090,6 +1093,8 @@ PT_DEV void path_step(const DScene& S, const PTFrameParams& P, PathRegs& r, cons
         const uint32_t numSamples = P.SamplesPerPass > 1 ? (uint32_t)P.SamplesPerPass : 1u;
         if (r.sampleIdx < numSamples) {
             path_start_sample(P, pixelX, pixelY, r, cn);
+        } else if (!INLINE_RESOLVE) {
+            r.state = PS_DONE;
         } else {
             const float fSamples = (float)numSamples;
             float4 o4;
@@ -1206,4 +1211,61 @@ PT_DEV bool ray_step(const DScene& S, RayState& r, ST& st, Counters& cn)
         }
     }
     return false;
+}
+
+// The same traversal in finer steps: one call does EITHER one triangle test (while the current triangle group is
+// not empty) OR pop + node step / group adoption.  Lanes that need a node step no longer wait for the lane with the
+// most triangles in its group; the per-ray operation sequence is unchanged.
+template <bool STATS, class ST>
+PT_DEV bool ray_microstep(const DScene& S, RayState& r, ST& st, Counters& cn)
+{
+    bool finished = false;
+    if (r.tg.y != 0u) {
+        uint32_t triangleIndex = 31u - (uint32_t)__clz((int)r.tg.y);
+        uint32_t triAddr = r.tg.x + triangleIndex * 3u;
+        intersect_triangle(S.tris, triAddr, r.o, r.d, r.hit);
+        if (STATS) cn.triTests++;
+        r.tg.y -= 1u << triangleIndex;
+        if (r.anyHit && r.hit.t < PT_FAR_PLANE) {
+            finished = true;
+            if (STATS && r.overflow) cn.overflows++;
+        }
+    } else {
+        if (r.ng.y <= 0x00FFFFFFu) {
+            if (r.sp > 0u) { --r.sp; r.ng = stack_pop(st, r.sp); }
+            else {
+                finished = true;
+                if (STATS && r.overflow) cn.overflows++;
+            }
+        }
+        if (!finished) {
+            if (r.ng.y > 0x00FFFFFFu) {
+                uint32_t mask = r.ng.y;
+                uint32_t childBitIndex = 31u - (uint32_t)__clz((int)mask);
+                uint32_t childNodeBaseIndex = r.ng.x;
+                r.ng.y &= ~(1u << childBitIndex);
+                if (r.ng.y > 0x00FFFFFFu) {
+                    stack_push(st, r.sp, r.ng);
+                    if (r.sp >= PT_BVH_STACK_SIZE) r.overflow = true;
+                    r.sp++;
+                    if (STATS) cn.maxStack = r.sp > cn.maxStack ? r.sp : cn.maxStack;
+                }
+                uint32_t slotIndex = (childBitIndex - 24u) ^ (r.octinv4 & 255u);
+                uint32_t relativeIndex = (uint32_t)__popc(mask & ~(0xFFFFFFFFu << slotIndex));
+                uint32_t childNodeIndex = childNodeBaseIndex + relativeIndex;
+                const uint4* np = S.nodes + (size_t)childNodeIndex * 5;
+                uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+                uint32_t hitmask = cwbvh_node_hitmask(r.o, r.invDir, r.octinv4, r.hit.t, n0, n1, n2, n3, n4);
+                if (STATS) cn.nodeVisits++;
+                r.ng.x = n1.x;
+                r.ng.y = (hitmask & 0xFF000000u) | (n0.w >> 24);
+                r.tg.x = n1.y;
+                r.tg.y = hitmask & 0x00FFFFFFu;
+            } else {
+                r.tg = r.ng;
+                r.ng = make_uint2(0u, 0u);
+            }
+        }
+    }
+    return finished;
 }

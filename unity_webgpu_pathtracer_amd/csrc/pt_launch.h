@@ -34,4 +34,6 @@ struct PTWfBuffers {
 uint32_t pt_wf_num_slots(const PTTileMap& tm);
 hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const float4* accumulated, float4* output,
                                const PTTileMap& tm, const PTWfBuffers& B, unsigned long long* gstats, bool fullStats,
-                               uint32_t* hostAlive, hipStream_t stream, uint32_t* launchesOut, int traceVariant);
+                               hipStream_t stream, hipEvent_t orderAfter, bool zeroOutputFirst,
+                               uint32_t* launchesOut, int traceVariant);
+#define PT_WF_SETS 2      // path-state sets = passes that can be in flight at once

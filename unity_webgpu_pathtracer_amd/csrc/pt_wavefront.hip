@@ -1,20 +1,23 @@
-// pt_wavefront.hip — schedule 1: the same per-pixel program as the megakernel, cut at the traversal calls.
+// pt_wavefront.hip — schedules 1-3: the same per-pixel program as the megakernel, cut at the traversal calls.
 //
 // Why: in one fused kernel the Disney-BSDF shading code sets the register budget (185 VGPRs -> 2 waves/SIMD, or
 // 128 with spills -> 4), and lanes that shade wait for lanes that traverse and vice versa (measured VALU lane
-// utilisation well under 40 %).  Here every pixel owns a SLOT of path state in HBM and a pass is a sequence of
-//     trace  : one lane per (slot, ray kind) -- lean CWBVH traversal only, high occupancy
-//     shade  : one lane per slot -- path_step() of pt_device.h: apply NEE, shade, roulette, next sample / write pixel
-// repeated until every pixel has finished its SamplesPerPass samples.  Samples of a pixel stay sequential (one RNG
-// chain per pixel per pass, PathTracer.compute:60,66), so a slot carries exactly one path at a time and the number
-// of iterations is about SamplesPerPass x (bounces + 1).
+// utilisation 19 %).  Here every pixel owns a SLOT of path state in HBM and a pass is
+//     init                     camera ray of the first sample into every slot
+//     N x [ trace ; shade ]    trace: lean CWBVH traversal only, 8 waves/SIMD, rays compacted into lanes per wave;
+//                              shade: path_step() of pt_device.h (apply NEE, shade, roulette, next sample)
+//     cleanup                  lanes whose pixel is still alive after N iterations run it to completion megakernel-style
+//     resolve                  out = (sum + accumulated * CurrentSample) / (CurrentSample + spp)   (PathTracer.compute:89-98)
+// Samples of a pixel stay sequential (one RNG chain per pixel per pass, PathTracer.compute:60,66), so a slot carries one
+// path at a time and a pass needs about SamplesPerPass x (bounces + 2) iterations.  N is that bound; pixels that need
+// more (alpha-skips add iterations without adding depth) are finished by the cleanup kernel, so a pass is a fixed,
+// HOST-SYNC-FREE sequence of launches.  Because the pixel write is decoupled (resolve), pass k+1 can start tracing on a
+// second state set and stream while pass k is still draining; only the tiny resolve kernels are ordered.
 //
-// There are NO queues and NO global atomics: rays are found by scanning the slot-indexed flag words (a ray of
-// kind k exists for slot s iff the flags say so), results go to slot-indexed arrays, and termination is a plain
-// store of "somebody is still alive" per iteration that the host polls every few iterations.  Work counters are
-// accumulated in per-wave rows (plain read-modify-write: one wave owns a row) and folded once per pass.
-// Every fp32 value and RNG draw is produced by the same device functions in the same per-path order as in
-// schedule 0, so frames and counters are bit-identical between the two schedules and to the oracle.
+// There are NO queues and NO global atomics in schedule 1: rays are found by scanning the slot-indexed flag words,
+// results go to slot-indexed arrays, work counters accumulate in per-wave rows (plain read-modify-write: one wave owns
+// a row) and are folded once per pass.  Every fp32 value and RNG draw is produced by the same device functions in the
+// same per-path order as in schedule 0, so frames and counters are bit-identical between schedules and to the oracle.
 #include "pt_device.h"
 #include "pt_launch.h"
 
@@ -123,8 +126,9 @@ __global__ __launch_bounds__(256, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace(DScene
 {
     __shared__ uint2 s_stack[PT_LDS_STACK][256];
     const uint32_t nb = B.numSlots >> 8;
-    const uint32_t kind = blockIdx.x / nb;
-    const uint32_t slot = (blockIdx.x % nb) * 256u + threadIdx.x;
+    const uint32_t vb = blockIdx.x;
+    const uint32_t kind = vb / nb;
+    const uint32_t slot = (vb % nb) * 256u + threadIdx.x;
     const uint32_t f = B.flags[slot];
     bool valid;
     if (kind == 0u) valid = fl_state(f) == PS_TRACE;
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(256, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace(DScene
         if (kind == 0u) { B.hit[slot] = make_float4(h.t, h.u, h.v, pt_asfloat(h.triIndex)); cn.closestRays++; }
         else { B.occl[(size_t)(kind - 1u) * B.numSlots + slot] = h.t < PT_FAR_PLANE ? 1 : 0; cn.shadowRays++; }
     }
-    flush_counters<STATS>(cn, B.statRows, (B.numSlots >> 6) + blockIdx.x * 4u + (threadIdx.x >> 6), threadIdx.x & 63u);
+    flush_counters<STATS>(cn, B.statRows, (B.numSlots >> 6) + vb * 4u + (threadIdx.x >> 6), threadIdx.x & 63u);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -163,6 +167,14 @@ __global__ __launch_bounds__(256, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace(DScene
 #endif
 #ifndef PT_WF_REFILL
 #define PT_WF_REFILL 16u        // refill when at least this many lanes are idle
+#endif
+#ifndef PT_WF_FLAT
+#define PT_WF_FLAT 0            // 1: ray_microstep (one triangle OR one node step per wave iteration), 0: ray_step
+#endif
+#if PT_WF_FLAT
+#define PT_WF_STEP ray_microstep
+#else
+#define PT_WF_STEP ray_step
 #endif
 #ifndef PT_WF_TRACE_BLOCK
 #define PT_WF_TRACE_BLOCK 64u   // threads per workgroup of the refill trace kernel (one wave: a finished wave frees its slot at once)
@@ -240,7 +252,7 @@ __global__ __launch_bounds__(PT_WF_TRACE_BLOCK, PT_WF_TRACE_MIN_WAVES) void pt_w
         const uint32_t stopAt = cursor < nItems ? PT_WF_REFILL : 64u;
         do {
             if (have) {
-                if (ray_step<STATS>(S, rs, st, cn)) {
+                if (PT_WF_STEP<STATS>(S, rs, st, cn)) {
                     if (myKind == 0u) B.hit[mySlot] = make_float4(rs.hit.t, rs.hit.u, rs.hit.v, pt_asfloat(rs.hit.triIndex));
                     else B.occl[(size_t)(myKind - 1u) * B.numSlots + mySlot] = rs.hit.t < PT_FAR_PLANE ? 1 : 0;
                     have = false;
@@ -348,7 +360,7 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_persist
         const uint32_t stopAt = more ? PT_WF_REFILL : 64u;
         do {
             if (have) {
-                if (ray_step<STATS>(S, rs, st, cn)) {
+                if (PT_WF_STEP<STATS>(S, rs, st, cn)) {
                     if (myKind == 0u) B.hit[mySlot] = make_float4(rs.hit.t, rs.hit.u, rs.hit.v, pt_asfloat(rs.hit.triIndex));
                     else B.occl[(size_t)(myKind - 1u) * B.numSlots + mySlot] = rs.hit.t < PT_FAR_PLANE ? 1 : 0;
                     have = false;
@@ -367,56 +379,148 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_persist
 #define PT_WF_SHADE_MIN_WAVES 3
 #endif
 
+// everything the shade step does for one slot (flags word f already read, state != DONE)
+PT_DEV void load_path(const PTWfBuffers& B, uint32_t slot, uint32_t f, PathRegs& r)
+{
+    r.state = fl_state(f);
+    r.hasPending = fl_pending(f);
+    r.env.valid = fl_env(f);
+    r.light.valid = fl_light(f);
+    r.green = (f >> 6) & 1u;
+    r.sampleIdx = (f >> 7) & 0xFFFu;
+    r.depth = f >> 19;
+    r.rng = B.rng[slot];
+    float4 q;
+    q = B.ro[slot]; r.ro = xyz(q); r.scatterPdf = q.w;
+    q = B.rd[slot]; r.rd = xyz(q); r.maxRoughness = q.w;
+    r.radiance = xyz(B.rad[slot]);
+    r.throughput = xyz(B.thr[slot]);
+    r.color = xyz(B.color[slot]);
+    r.env.dir = mk3(0.0f); r.light.dir = mk3(0.0f); r.neeOrigin = mk3(0.0f);
+    r.env.contribution = mk3(0.0f); r.light.contribution = mk3(0.0f); r.pendThroughput = mk3(0.0f);
+    if (r.hasPending) {
+        r.env.contribution = xyz(B.envC[slot]);
+        r.light.contribution = xyz(B.lightC[slot]);
+        r.pendThroughput = xyz(B.pthr[slot]);
+    }
+}
+
+template <bool STATS>
+PT_DEV bool shade_slot(const DScene& S, const PTFrameParams& P, const PTTileMap& tm, const PTWfBuffers& B, uint32_t slot, uint32_t f,
+                       Counters& cn)
+{
+    uint32_t px, py;
+    slot_to_pixel(tm, slot, px, py);
+    PathRegs r;
+    load_path(B, slot, f, r);
+    bool occEnv = false, occLight = false;
+    if (r.hasPending) {
+        occEnv = B.occl[slot] != 0;
+        occLight = B.occl[(size_t)B.numSlots + slot] != 0;
+    }
+    TraceHit ch;
+    ch.t = PT_FAR_PLANE; ch.u = 0.0f; ch.v = 0.0f; ch.triIndex = 0u;
+    if (r.state == PS_TRACE) {
+        float4 h = B.hit[slot];
+        ch.t = h.x; ch.u = h.y; ch.v = h.z; ch.triIndex = pt_asuint(h.w);
+    }
+    path_step<STATS, false>(S, P, r, ch, occEnv, occLight, px, py, py * P.OutputWidth + px, nullptr, nullptr, cn);
+    store_path(B, slot, r, r.hasPending);
+    return r.state != PS_DONE;
+}
+
+// one lane per slot.  (Compacting the live slots into full waves was tried and is slower: the kernel is a chain of
+// dependent fetches at 3 waves/SIMD, so fewer, longer waves lose more than the idle lanes cost.)
 template <bool STATS>
 __global__ __launch_bounds__(256, PT_WF_SHADE_MIN_WAVES) void pt_wf_shade(DScene S, PTFrameParams P, PTTileMap tm, PTWfBuffers B,
-                                                                         const float4* __restrict__ accumulated,
-                                                                         float4* __restrict__ output, uint32_t iteration)
+                                                                         uint32_t iteration)
 {
-    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
-    if (blockIdx.x == 0u && threadIdx.x < PT_WF_SHARDS) B.chunkHeads[threadIdx.x * 32u] = 0u;   // for the next trace launch
+    const uint32_t vb = blockIdx.x;
+    const uint32_t slot = vb * 256u + threadIdx.x;
+    if (vb == 0u && threadIdx.x < PT_WF_SHARDS) B.chunkHeads[threadIdx.x * 32u] = 0u;   // for the next trace launch (schedule 3)
     const uint32_t f = B.flags[slot];
     Counters cn = {};
     bool alive = false;
-    if (fl_state(f) != PS_DONE) {
-        uint32_t px, py;
-        slot_to_pixel(tm, slot, px, py);
-        PathRegs r;
-        r.state = fl_state(f);
-        r.hasPending = fl_pending(f);
-        r.env.valid = fl_env(f);
-        r.light.valid = fl_light(f);
-        r.green = (f >> 6) & 1u;
-        r.sampleIdx = (f >> 7) & 0xFFFu;
-        r.depth = f >> 19;
-        r.rng = B.rng[slot];
-        float4 q;
-        q = B.ro[slot]; r.ro = xyz(q); r.scatterPdf = q.w;
-        q = B.rd[slot]; r.rd = xyz(q); r.maxRoughness = q.w;
-        r.radiance = xyz(B.rad[slot]);
-        r.throughput = xyz(B.thr[slot]);
-        r.color = xyz(B.color[slot]);
-        r.env.dir = mk3(0.0f); r.light.dir = mk3(0.0f); r.neeOrigin = mk3(0.0f);
-        r.env.contribution = mk3(0.0f); r.light.contribution = mk3(0.0f); r.pendThroughput = mk3(0.0f);
-        bool occEnv = false, occLight = false;
-        if (r.hasPending) {
-            r.env.contribution = xyz(B.envC[slot]);
-            r.light.contribution = xyz(B.lightC[slot]);
-            r.pendThroughput = xyz(B.pthr[slot]);
-            occEnv = B.occl[slot] != 0;
-            occLight = B.occl[(size_t)B.numSlots + slot] != 0;
+    if (fl_state(f) != PS_DONE) alive = shade_slot<STATS>(S, P, tm, B, slot, f, cn);
+    if (__any(alive) && (threadIdx.x & 63u) == 0u) B.aliveFlags[iteration] = 1u;     // diagnostics: last iteration anybody needed
+    flush_counters<STATS>(cn, B.statRows, vb * 4u + (threadIdx.x >> 6), threadIdx.x & 63u);
+}
+
+// cleanup: pixels still alive after the fixed number of iterations are run to completion here, one lane per slot with
+// the megakernel's loop (trace <= 3 rays, path_step, repeat).  Normally a handful of lanes; correctness for any path length.
+template <bool STATS>
+__global__ __launch_bounds__(256, 2) void pt_wf_cleanup(DScene S, PTFrameParams P, PTTileMap tm, PTWfBuffers B)
+{
+    __shared__ uint2 s_stack[PT_LDS_STACK][256];
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t f = B.flags[slot];
+    Counters cn = {};
+    if (__any(fl_state(f) != PS_DONE)) {
+        if (fl_state(f) != PS_DONE) {
+            uint32_t px, py;
+            slot_to_pixel(tm, slot, px, py);
+            PathRegs r;
+            load_path(B, slot, f, r);
+            if (r.hasPending) {
+                r.neeOrigin = xyz(B.neeO[slot]);
+                r.env.dir = xyz(B.envD[slot]);
+                r.light.dir = xyz(B.lightD[slot]);
+            }
+            TravStack st;
+            st.lds = &s_stack[0][threadIdx.x];
+            st.stride = 256u;
+            while (r.state != PS_DONE) {
+                TraceHit ch;
+                ch.t = PT_FAR_PLANE; ch.u = 0.0f; ch.v = 0.0f; ch.triIndex = 0u;
+                bool occEnv = false, occLight = false;
+                if (r.hasPending && r.env.valid != 0u) {
+                    TraceHit h; h.t = PT_FAR_PLANE; h.u = 0.0f; h.v = 0.0f; h.triIndex = 0u;
+                    traverse_cwbvh<STATS>(S, r.neeOrigin, r.env.dir, true, h, st, cn);
+                    occEnv = h.t < PT_FAR_PLANE; cn.shadowRays++;
+                }
+                if (r.hasPending && r.light.valid != 0u) {
+                    TraceHit h; h.t = PT_FAR_PLANE; h.u = 0.0f; h.v = 0.0f; h.triIndex = 0u;
+                    traverse_cwbvh<STATS>(S, r.neeOrigin, r.light.dir, true, h, st, cn);
+                    occLight = h.t < PT_FAR_PLANE; cn.shadowRays++;
+                }
+                if (r.state == PS_TRACE) {
+                    traverse_cwbvh<STATS>(S, r.ro, r.rd, false, ch, st, cn);
+                    cn.closestRays++;
+                }
+                path_step<STATS, false>(S, P, r, ch, occEnv, occLight, px, py, py * P.OutputWidth + px, nullptr, nullptr, cn);
+            }
+            B.flags[slot] = pack_flags(r);
+            B.color[slot] = f4(r.color, 0.0f);
         }
-        TraceHit ch;
-        ch.t = PT_FAR_PLANE; ch.u = 0.0f; ch.v = 0.0f; ch.triIndex = 0u;
-        if (r.state == PS_TRACE) {
-            float4 h = B.hit[slot];
-            ch.t = h.x; ch.u = h.y; ch.v = h.z; ch.triIndex = pt_asuint(h.w);
-        }
-        path_step<STATS>(S, P, r, ch, occEnv, occLight, px, py, py * P.OutputWidth + px, accumulated, output, cn);
-        store_path(B, slot, r, r.hasPending);
-        alive = r.state != PS_DONE;
     }
-    if (__any(alive) && (threadIdx.x & 63u) == 0u) B.aliveFlags[iteration] = 1u;     // plain store; polled by the host
     flush_counters<STATS>(cn, B.statRows, blockIdx.x * 4u + (threadIdx.x >> 6), threadIdx.x & 63u);
+}
+
+// resolve: the pixel write of PathTracer.compute:89-98, applied to every slot's sample sum
+__global__ __launch_bounds__(256) void pt_wf_resolve(PTFrameParams P, PTTileMap tm, PTWfBuffers B, const float4* __restrict__ accumulated,
+                                                     float4* __restrict__ output)
+{
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    uint32_t px, py;
+    Counters cn = {};
+    if (slot < B.numSlots && slot_to_pixel(tm, slot, px, py)) {
+        const uint32_t pixelIndex = py * P.OutputWidth + px;
+        const uint32_t numSamples = P.SamplesPerPass > 1 ? (uint32_t)P.SamplesPerPass : 1u;
+        const float fSamples = (float)numSamples;
+        const v3 color = xyz(B.color[slot]);
+        v3 acc;
+        if (P.CurrentSample > 0u) {
+            float4 a = accumulated[pixelIndex];
+            cn.pixelsRead++;
+            float cs = (float)P.CurrentSample;
+            acc = (color + mk3(a.x, a.y, a.z) * cs) / (cs + fSamples);
+        } else {
+            acc = color / fSamples;
+        }
+        output[pixelIndex] = make_float4(acc.x, acc.y, acc.z, 1.0f);
+        cn.pixelsWritten++;
+    }
+    flush_counters<false>(cn, B.statRows, blockIdx.x * 4u + (threadIdx.x >> 6), threadIdx.x & 63u);
 }
 
 // fold the per-wave rows into the context's 14 counters (PTStats order) and clear them
@@ -452,12 +556,14 @@ uint32_t pt_wf_num_slots(const PTTileMap& tm)
     return bpr * tm.blocksY * 256u;
 }
 
+// One pass = a fixed sequence of launches on `stream`, no host synchronisation (see the file header).
+// `orderAfter` (may be null) is the event of the previous pass's resolve: this pass's resolve reads that pass's output as
+// AccumulatedOutput and, with ping-pong frames, overwrites the frame that resolve was still reading.
 hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const float4* accumulated, float4* output,
                                const PTTileMap& tm, const PTWfBuffers& B, unsigned long long* gstats, bool fullStats,
-                               uint32_t* hostAlive, hipStream_t stream, uint32_t* launchesOut, int traceVariant)
+                               hipStream_t stream, hipEvent_t orderAfter, bool zeroOutputFirst,
+                               uint32_t* launchesOut, int traceVariant)
 {
-    const uint32_t slotsPerBlock = PT_WF_RANGE * (PT_WF_TRACE_BLOCK / 64u);
-    const uint32_t refillBlocks = (B.numSlots + slotsPerBlock - 1u) / slotsPerBlock;
     const uint32_t nb = B.numSlots >> 8;
     uint32_t launches = 0;
     hipError_t e;
@@ -465,10 +571,13 @@ hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const fl
     hipLaunchKernelGGL(pt_wf_init, dim3(nb), dim3(256), 0, stream, P, tm, B);
     launches++;
     const uint32_t spp = P.SamplesPerPass > 1 ? (uint32_t)P.SamplesPerPass : 1u;
-    const uint32_t firstCheck = spp * 2u;        // no pixel can finish before `spp` iterations; most need far more
-    uint32_t it = 0;
-    for (;; ++it) {
-        if (it >= B.maxIterations) return hipErrorLaunchFailure;     // bounded: never spin forever
+    const uint32_t bounces = P.MaxRayBounces > 1u ? P.MaxRayBounces : 1u;
+    // a sample needs at most (bounces + 1) closest-hit iterations + 1 to apply its last NEE; alpha-skips beyond that go to cleanup
+    uint32_t iterations = spp * (bounces + 2u) + 4u;
+    if (iterations > B.maxIterations) iterations = B.maxIterations;
+    const uint32_t traceWavesPerBlock = PT_WF_TRACE_BLOCK / 64u;
+    const uint32_t refillBlocks = (B.numSlots + PT_WF_RANGE * traceWavesPerBlock - 1u) / (PT_WF_RANGE * traceWavesPerBlock);
+    for (uint32_t it = 0; it < iterations; ++it) {
         if (traceVariant == 0) {
             const uint32_t numChunks = (B.numSlots + PT_WF_CHUNK - 1u) / PT_WF_CHUNK;
             uint32_t waves = B.residentWaves;
@@ -482,17 +591,18 @@ hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const fl
             if (fullStats) hipLaunchKernelGGL(pt_wf_trace<true>, dim3(nb * 3u), dim3(256), 0, stream, S, B);
             else hipLaunchKernelGGL(pt_wf_trace<false>, dim3(nb * 3u), dim3(256), 0, stream, S, B);
         }
-        if (fullStats) hipLaunchKernelGGL(pt_wf_shade<true>, dim3(nb), dim3(256), 0, stream, S, P, tm, B, accumulated, output, it);
-        else hipLaunchKernelGGL(pt_wf_shade<false>, dim3(nb), dim3(256), 0, stream, S, P, tm, B, accumulated, output, it);
+        if (fullStats) hipLaunchKernelGGL(pt_wf_shade<true>, dim3(nb), dim3(256), 0, stream, S, P, tm, B, it);
+        else hipLaunchKernelGGL(pt_wf_shade<false>, dim3(nb), dim3(256), 0, stream, S, P, tm, B, it);
         launches += 2;
-        if (it >= firstCheck && ((it - firstCheck) & 3u) == 0u) {
-            if ((e = hipMemcpyAsync(hostAlive, B.aliveFlags + it, sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
-            if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
-            if (*hostAlive == 0u) break;
-        }
     }
+    if (fullStats) hipLaunchKernelGGL(pt_wf_cleanup<true>, dim3(nb), dim3(256), 0, stream, S, P, tm, B);
+    else hipLaunchKernelGGL(pt_wf_cleanup<false>, dim3(nb), dim3(256), 0, stream, S, P, tm, B);
+    if (orderAfter && (e = hipStreamWaitEvent(stream, orderAfter, 0)) != hipSuccess) return e;
+    if (zeroOutputFirst &&
+        (e = hipMemsetAsync(output, 0, (size_t)P.OutputWidth * P.OutputHeight * sizeof(float4), stream)) != hipSuccess) return e;
+    hipLaunchKernelGGL(pt_wf_resolve, dim3(nb), dim3(256), 0, stream, P, tm, B, accumulated, output);
     hipLaunchKernelGGL(pt_wf_fold_rows, dim3(256), dim3(256), 0, stream, B.statRows, B.numStatRows, gstats);
-    launches++;
+    launches += 3;
     if (launchesOut) *launchesOut = launches;
     return hipGetLastError();
 }
