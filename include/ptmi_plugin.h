@@ -204,6 +204,10 @@ PT_API int PTResetTimings(PTContext* ctx);
  *   2  wavefront with the plain one-ray-per-lane trace kernel
  *   3  wavefront with the persistent dynamic-chunk trace kernel */
 PT_API int PTSetSchedule(PTContext* ctx, int schedule);
+/* Wavefront schedules: number of trace+shade iterations launched per pass before the cleanup kernel finishes whatever is
+ * still alive.  0 (default) = SamplesPerPass * (MaxRayBounces + 2) + 4.  Any value gives the same frame; it only moves
+ * work between the wavefront kernels and the cleanup kernel (tuning / test knob). */
+PT_API int PTSetWavefrontIterations(PTContext* ctx, int iterations);
 
 /* Text of the last error on the calling thread ("" if none). */
 PT_API const char* PTGetLastError(void);

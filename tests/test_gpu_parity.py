@@ -175,3 +175,83 @@ def test_nan_nee_ray_is_a_cheap_miss(oracle, schedule):
     _stats_equal(pt.stats(), sq, ALL_COUNTERS)
     assert sf.nodeVisits > sq.nodeVisits + 1000
     pt.close()
+
+
+@pytest.mark.parametrize("iterations", [1, 3, 7])
+def test_wavefront_cleanup_kernel_finishes_any_path(oracle, iterations):
+    """With too few wavefront iterations almost every pixel is finished by the cleanup kernel (the megakernel loop
+    resumed from slot state).  Frame and counters must not change."""
+    s = scenes.material_zoo()
+    pt = PathTracer(s, width=96, height=72, samplesPerPass=3, schedule=1)
+    pt.set_wavefront_iterations(iterations)
+    pt.set_stats_level(1)
+    p = pt.params(seed=0xBEEF)
+    pt.render_pass(p)
+    gpu = pt.readback()
+    ref, st = _oracle_frame(oracle, pt, p, shadow_any_hit=True)
+    _, nbad = _compare(gpu, ref, f"cleanup after {iterations} iterations")
+    assert nbad == 0
+    _stats_equal(pt.stats(), st, ALL_COUNTERS)
+    pt.close()
+
+
+@pytest.mark.parametrize("schedule", [0, 1])
+def test_pipelined_passes_without_host_sync(oracle, schedule):
+    """Six progressive passes issued back to back (the wavefront schedule overlaps them on separate state sets and
+    streams; only the resolves are ordered).  The final frame must equal six sequential oracle passes bit for bit."""
+    s = scenes.cornell_box()
+    pt = PathTracer(s, width=160, height=96, samplesPerPass=2, schedule=schedule)
+    seeds = [(0x12345678 + k * 0x9E3779B9) & 0xFFFFFFFF for k in range(6)]
+    params = []
+    for k in range(6):
+        params.append(pt.params(seeds[k]))
+        pt.OnRenderImage(seeds[k])            # no readback / synchronize in between
+    gpu = pt.readback()
+    ref = None
+    for p in params:
+        ref, _ = _oracle_frame(oracle, pt, p, accumulated=ref)
+    _, nbad = _compare(gpu, ref, f"6 pipelined passes, schedule {schedule}")
+    assert nbad == 0
+    pt.close()
+
+
+def test_render_pass_to_caller_buffers(oracle):
+    """PTRenderPassTo with caller-owned device frames (torch tensors), ping-ponged by the caller as bench.py does."""
+    import torch
+    s = scenes.cornell_box()
+    w, h = 128, 80
+    pt = PathTracer(s, width=w, height=h, samplesPerPass=2)
+    frames = [torch.zeros((h, w, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    ref, cur = None, 0
+    for k in range(4):
+        p = scenes.frame_params(s, w, h, spp=2, current_sample=2 * k, seed=1000 + k)
+        pt.render_pass_to(p, frames[cur].data_ptr(), frames[1 - cur].data_ptr() if k else 0)
+        ref, _ = _oracle_frame(oracle, pt, p, accumulated=ref)
+        cur = 1 - cur
+    pt.synchronize()
+    gpu = frames[1 - cur].cpu().numpy()
+    _, nbad = _compare(gpu, ref, "PTRenderPassTo x4")
+    assert nbad == 0
+    pt.close()
+
+
+def test_plain_c_host(tmp_path, oracle):
+    """host/pt_host.c: the plain-C host renders the Cornell box through the C-ABI; its frame equals the oracle's."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "host")], stdout=subprocess.DEVNULL)
+    out = str(tmp_path / "frame.f32")
+    subprocess.check_call([os.path.join(root, "host", "pt_host"), "64", "48", "2", "2", out], cwd=root, stdout=subprocess.DEVNULL)
+    gpu = np.fromfile(out, dtype=np.float32).reshape(48, 64, 4)
+    s = scenes.cornell_box()
+    from unity_webgpu_pathtracer_amd import plugin
+    nodes, tris = plugin.build_cwbvh(s.vertices)
+    b = oracle.SceneBuffers(s, nodes, tris)
+    ref = None
+    for k in range(2):
+        p = scenes.frame_params(s, 64, 48, spp=2, current_sample=2 * k, seed=(0x12345678 + k * 0x9E3779B9) & 0xFFFFFFFF)
+        ref, _ = oracle.render(b, p, accumulated=ref)
+    # the C host computes its camera matrices in fp32 C arithmetic, the Python host in fp64 numpy: allow that difference
+    assert np.abs(gpu - ref).mean() < 0.05 and gpu.shape == ref.shape and np.isfinite(gpu).all()

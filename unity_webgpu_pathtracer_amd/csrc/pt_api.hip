@@ -64,6 +64,7 @@ struct PTContext {
         hipEvent_t callEv = nullptr, done = nullptr;
     } sets[PT_WF_SETS];
     uint32_t nextSet = 0;
+    uint32_t wfIterations = 0;                  // 0 = automatic
 };
 
 namespace {
@@ -204,7 +205,7 @@ int render_to(PTContext* c, const PTFrameParams* p, float4* dOut, const float4* 
         HIP_TRY(hipEventRecord(set.callEv, c->stream));
         if (c->profiling) HIP_TRY(hipEventRecord(ep.start, set.stream));
         HIP_TRY(pt_launch_wavefront(c->scene, *p, dAcc, dOut, tm, set.wf, c->dStats, c->statsLevel > 0, set.stream, set.callEv,
-                                    c->world > 1, &launches, c->schedule == 1 ? 2 : (c->schedule == 2 ? 1 : 0)));
+                                    c->world > 1, &launches, c->schedule == 1 ? 2 : (c->schedule == 2 ? 1 : 0), c->wfIterations));
         if (c->profiling) HIP_TRY(hipEventRecord(ep.stop, set.stream));
         HIP_TRY(hipEventRecord(set.done, set.stream));
         HIP_TRY(hipStreamWaitEvent(c->stream, set.done, 0));          // consumers of the context stream see the finished frame
@@ -426,6 +427,13 @@ PT_API int PTSetSchedule(PTContext* c, int schedule)
     if (schedule < 0 || schedule > 3)
         return fail(PT_ERR_UNSUPPORTED, "unknown schedule (0 = megakernel, 1 = wavefront + refill trace, 2 = wavefront, one ray per lane, 3 = wavefront + persistent dynamic-chunk trace)");
     c->schedule = schedule;
+    return PT_OK;
+}
+
+PT_API int PTSetWavefrontIterations(PTContext* c, int iterations)
+{
+    if (!c || iterations < 0) return fail(PT_ERR_INVALID_ARG, "ctx == NULL or iterations < 0");
+    c->wfIterations = (uint32_t)iterations;
     return PT_OK;
 }
 

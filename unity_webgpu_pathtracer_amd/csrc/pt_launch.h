@@ -35,5 +35,8 @@ uint32_t pt_wf_num_slots(const PTTileMap& tm);
 hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const float4* accumulated, float4* output,
                                const PTTileMap& tm, const PTWfBuffers& B, unsigned long long* gstats, bool fullStats,
                                hipStream_t stream, hipEvent_t orderAfter, bool zeroOutputFirst,
-                               uint32_t* launchesOut, int traceVariant);
-#define PT_WF_SETS 2      // path-state sets = passes that can be in flight at once
+                               uint32_t* launchesOut, int traceVariant, uint32_t iterationsOverride);
+#ifndef PT_WF_SETS
+#define PT_WF_SETS 3
+#endif
+//      // path-state sets = passes that can be in flight at once

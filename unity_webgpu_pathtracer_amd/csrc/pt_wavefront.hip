@@ -562,7 +562,7 @@ uint32_t pt_wf_num_slots(const PTTileMap& tm)
 hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const float4* accumulated, float4* output,
                                const PTTileMap& tm, const PTWfBuffers& B, unsigned long long* gstats, bool fullStats,
                                hipStream_t stream, hipEvent_t orderAfter, bool zeroOutputFirst,
-                               uint32_t* launchesOut, int traceVariant)
+                               uint32_t* launchesOut, int traceVariant, uint32_t iterationsOverride)
 {
     const uint32_t nb = B.numSlots >> 8;
     uint32_t launches = 0;
@@ -573,7 +573,7 @@ hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const fl
     const uint32_t spp = P.SamplesPerPass > 1 ? (uint32_t)P.SamplesPerPass : 1u;
     const uint32_t bounces = P.MaxRayBounces > 1u ? P.MaxRayBounces : 1u;
     // a sample needs at most (bounces + 1) closest-hit iterations + 1 to apply its last NEE; alpha-skips beyond that go to cleanup
-    uint32_t iterations = spp * (bounces + 2u) + 4u;
+    uint32_t iterations = iterationsOverride ? iterationsOverride : spp * (bounces + 2u) + 4u;
     if (iterations > B.maxIterations) iterations = B.maxIterations;
     const uint32_t traceWavesPerBlock = PT_WF_TRACE_BLOCK / 64u;
     const uint32_t refillBlocks = (B.numSlots + PT_WF_RANGE * traceWavesPerBlock - 1u) / (PT_WF_RANGE * traceWavesPerBlock);

@@ -168,6 +168,9 @@ class PathTracer:
     def set_schedule(self, schedule: int):
         plugin.check(self.lib.PTSetSchedule(self.ctx, schedule))
 
+    def set_wavefront_iterations(self, n: int):
+        plugin.check(self.lib.PTSetWavefrontIterations(self.ctx, n))
+
     def close(self):
         if self.ctx:
             self.lib.PTDestroy(self.ctx)
