@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--bounces", type=int, default=4)
     ap.add_argument("--schedule", type=int, default=1, help="0 megakernel, 1 wavefront (default), 2/3 wavefront variants")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alg-replay", action="store_true", help="profiling runs: skip the untimed full-counter replay (roofline.achieved is then null)")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads reported under 'other_workloads'")
     args = ap.parse_args()
 
@@ -191,7 +192,7 @@ def main():
             "pass_span_ms": tm.kernelMsTotal / max(1, tm.passes),  # first-launch-to-resolve span of one pass
             "tris": scene.tri_count,
         }
-        if full and rank == 0:
+        if full and rank == 0 and not args.no_alg_replay:
             # algorithmic bytes: replay the same timed steps once, untimed, with the full-counter kernel variant
             pt.set_stats_level(1)
             pt.reset_stats()
@@ -215,6 +216,9 @@ def main():
     out = None
     if rank == 0:
         kernel_s = main_res["kernel_ms"] / 1e3
+        main_res.setdefault("alg_bytes_per_launch", 0.0)
+        main_res.setdefault("counters_per_launch", {})
+        main_res.setdefault("max_stack_depth", 0)
         achieved = main_res["alg_bytes_per_launch"] / kernel_s / 1e9 if kernel_s > 0 else 0.0
         traffic = None
         tj = os.path.join(ROOT, "profiles", "hbm_traffic.json")

@@ -19,6 +19,31 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def short(name):
+    import re
+    m = re.search(r"(pt_\w+)(<\w+>)?", name)
+    return (m.group(1) + (m.group(2) or "")) if m else name[:40]
+
+
+def per_pass(rows, value_of):
+    """Sum a per-dispatch quantity over the kernels of each pass.  A pass is one pt_megakernel dispatch, or the
+    pt_wf_init ... pt_wf_fold_rows sequence of the wavefront schedule (passes overlap in time but every dispatch
+    belongs to exactly one pass; with overlapping passes dispatches are attributed by their order per kernel name)."""
+    totals, per_kernel = [], {}
+    mk = [value_of(r) for r in rows if "pt_megakernel" in r["Kernel_Name"]]
+    if mk:
+        return mk, {"pt_megakernel": sum(mk) / len(mk)}
+    n_pass = sum(1 for r in rows if "pt_wf_init" in r["Kernel_Name"])
+    if n_pass == 0:
+        return [], {}
+    for r in rows:
+        if "pt_wf_" in r["Kernel_Name"]:
+            k = short(r["Kernel_Name"])
+            per_kernel[k] = per_kernel.get(k, 0.0) + value_of(r)
+    total = sum(per_kernel.values())
+    return [total / n_pass] * n_pass, {k: v / n_pass for k, v in per_kernel.items()}
+
+
 def main():
     tag = sys.argv[1]
     workload = sys.argv[2] if len(sys.argv) > 2 else "sponza"
@@ -32,30 +57,34 @@ def main():
         rows = [r for r in csv.DictReader(open(trace[0])) if "pt_" in r["Kernel_Name"]]
         per = {}
         for r in rows:
-            per.setdefault(r["Kernel_Name"].split("(")[0], []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
-        out["kernel_ms"] = {k: {"calls": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)} for k, v in per.items()}
-        r0 = rows[0]
-        out["resources"] = {k: r0.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size_X", "Grid_Size_X")}
+            per.setdefault(short(r["Kernel_Name"]), []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+        out["kernel_ms"] = {k: {"calls": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v), "total": sum(v)} for k, v in per.items()}
+        res = {}
+        for r in rows:
+            res[short(r["Kernel_Name"])] = {k: r.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size_X", "Grid_Size_X")}
+        out["resources"] = res
+        t0 = min(int(r["Start_Timestamp"]) for r in rows)
+        t1 = max(int(r["End_Timestamp"]) for r in rows)
+        n_pass = sum(1 for r in rows if "pt_wf_init" in r["Kernel_Name"] or "pt_megakernel" in r["Kernel_Name"])
+        out["passes"] = n_pass
+        out["span_ms_per_pass"] = (t1 - t0) / 1e6 / max(1, n_pass)
     pmc = {}
     for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         f = glob.glob(os.path.join(base, f"{tag}_{kind}", "*", "*_counter_collection.csv"))
         if not f:
             continue
-        vals = {}
-        for r in csv.DictReader(open(f[0])):
-            if "pt_" in r["Kernel_Name"] and r["Counter_Name"] == counter:
-                vals.setdefault(r["Kernel_Name"].split("(")[0], []).append(float(r["Counter_Value"]))
-        pmc[counter] = {k: {"launches": len(v), "mean_KiB": sum(v) / len(v)} for k, v in vals.items()}
+        rows = [r for r in csv.DictReader(open(f[0])) if "pt_" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+        passes, per_kernel = per_pass(rows, lambda r: float(r["Counter_Value"]))
+        pmc[counter] = {"KiB_per_pass": sum(passes) / max(1, len(passes)), "passes": len(passes), "KiB_per_pass_by_kernel": per_kernel}
     out["pmc"] = pmc
-    dom = None
     if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
-        dom = max(pmc["FETCH_SIZE"], key=lambda k: pmc["FETCH_SIZE"][k]["mean_KiB"])
-        fetch = pmc["FETCH_SIZE"][dom]["mean_KiB"] * 1024
-        write = pmc["WRITE_SIZE"].get(dom, {"mean_KiB": 0})["mean_KiB"] * 1024
-        out["hbm_bytes_per_launch"] = {"kernel": dom, "fetch_raw": fetch, "fetch_x2_upper": 2 * fetch, "write": write,
-                                       "total_raw": fetch + write, "total_upper": 2 * fetch + write}
-        json.dump({"workload": workload, "n_gpus": 1, "kernel": dom, "bytes_per_launch": round(2 * fetch + write),
-                   "note": "FETCH_SIZE x2 (gfx950 correction, upper estimate for scattered 16-B reads) + WRITE_SIZE, separate --pmc passes; source profiles/%s_pmc.json" % tag},
+        fetch = pmc["FETCH_SIZE"]["KiB_per_pass"] * 1024
+        write = pmc["WRITE_SIZE"]["KiB_per_pass"] * 1024
+        out["hbm_bytes_per_pass"] = {"fetch_raw": fetch, "fetch_x2_upper": 2 * fetch, "write": write,
+                                     "total_raw": fetch + write, "total_upper": 2 * fetch + write}
+        json.dump({"workload": workload, "n_gpus": 1, "bytes_per_launch": round(2 * fetch + write),
+                   "note": "per pass (all kernels of the schedule): FETCH_SIZE x2 (gfx950 correction; upper estimate for scattered 16-B reads) "
+                           "+ WRITE_SIZE, separate --pmc passes; source profiles/%s_pmc.json" % tag},
                   open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
     json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
