@@ -73,7 +73,7 @@ typedef struct PTContext PTContext;   /* opaque; one per GPU (one process per GP
 /* Feature bits = the reference's shader keywords (PathTracer.compute:6-9). */
 #define PT_FEATURE_HAS_LIGHTS    0x1u   /* HAS_LIGHTS   (PathTracer.cs:372,469) */
 #define PT_FEATURE_HAS_TEXTURES  0x2u   /* HAS_TEXTURES (PathTracer.cs:185)     */
-#define PT_FEATURE_HAS_TLAS      0x4u   /* HAS_TLAS     (BVHScene.cs:145-149); not implemented yet -> PT_ERR_UNSUPPORTED */
+#define PT_FEATURE_HAS_TLAS      0x4u   /* HAS_TLAS     (BVHScene.cs:145-149): two-level traversal, util/tlas.hlsl       */
 
 /* The buffers BVHScene.PrepareShader binds (BVHScene.cs:151-166) + Lights (PathTracer.cs:471).
  * All pointers are HOST pointers; PTSetScene copies them into HBM. */
@@ -85,6 +85,11 @@ typedef struct PTSceneDesc {
     const void*     lights;          uint32_t lightCount;     uint32_t _pad1;  /* PTLight[] "Lights" + LightCount */
     const uint32_t* textureData;     uint64_t textureDataUints;  /* "TextureData": K x {w,h,offset,0} then texels */
     uint32_t        features;        uint32_t _pad2;             /* PT_FEATURE_* */
+    /* HAS_TLAS only (BVHScene.cs:155-160, 700-758).  bvhNodes / bvhTris / triAttrs then hold the per-mesh BLASes back to back
+     * and each PTGpuInstance carries its offsets into them. */
+    const float*    tlasData;        uint64_t tlasDataFloats;    /* "TLASData": PTTlasNode[] (16 floats each) then the instance indices */
+    uint32_t        tlasIndexOffset; uint32_t instanceCount;     /* "TLASIndexOffset" (in floats); number of PTGpuInstance           */
+    const void*     gpuInstances;                                /* PTGpuInstance[]        "BLASInstances"                            */
 } PTSceneDesc;
 
 /* The uniform block PathTracer.OnRenderImage sets every frame (PathTracer.cs:230-249;
@@ -134,6 +139,8 @@ typedef struct PTStats {
     uint64_t pixelsRead;           /* AccumulatedOutput texels read (16 B each)            */
     uint64_t maxStackDepth;        /* deepest traversal stack seen (reference limit is 32) */
     uint64_t stackOverflows;       /* rays that would have exceeded BVH_STACK_SIZE         */
+    uint64_t tlasNodeVisits;       /* HAS_TLAS: TLAS nodes read (64 B each)                */
+    uint64_t instanceVisits;       /* HAS_TLAS: BLAS instances entered (144 B each)        */
 } PTStats;
 
 /* Device-side timing of the render kernels, measured with HIP events recorded on the

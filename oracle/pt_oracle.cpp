@@ -109,7 +109,9 @@ struct SceneView {
     const PTMaterialData* materials; uint32_t materialCount;
     const PTLight* lights; int32_t lightCount;
     const uint32_t* tex; uint64_t texUints;
-    bool hasLights, hasTextures;
+    const float* tlas; uint64_t tlasFloats; uint32_t tlasIndexOffset;
+    const PTGpuInstance* instances; uint32_t instanceCount;
+    bool hasLights, hasTextures, hasTlas;
 };
 
 struct Ctx {
@@ -327,6 +329,201 @@ done:
 }
 
 // ------------------------------------------------------------------------------------------
+// util/tlas.hlsl — HAS_TLAS variant: 2-wide TLAS over instances, each instance a CWBVH in its local space
+// ------------------------------------------------------------------------------------------
+// tlas.hlsl:22-59.  Differences from util/bvh.hlsl:23-59: accept distance > 0 (not 1e-4), triIndex gets the
+// instance's attribute offset, returns whether THIS call accepted the triangle.
+inline bool IntersectTriangleInst(Ctx& c, const PTGpuInstance& inst, uint32_t triAddr, const Ray& ray, RayHit& hit)
+{
+    const PTFloat4* t = c.S->tris + triAddr;
+    f3 v0 = V3(t[2].x, t[2].y, t[2].z);
+    f3 e1 = V3(t[1].x, t[1].y, t[1].z);
+    f3 e2 = V3(t[0].x, t[0].y, t[0].z);
+    c.st.triTests++;
+    bool hitFound = false;
+    f3 r = cross(ray.direction, e2);
+    float a = dot(e1, r);
+    if (pt_abs(a) > 0.0000001f) {
+        float f = 1.0f / a;
+        f3 s = ray.origin - v0;
+        float u = f * dot(s, r);
+        if (u >= 0.0f && u <= 1.0f) {
+            f3 q = cross(s, e1);
+            float v = f * dot(ray.direction, q);
+            if (v >= 0.0f && u + v <= 1.0f) {
+                float d = f * dot(e2, q);
+                if (d > 0.0f && d < hit.distance) {
+                    hit.barycentric = {u, v};
+                    hit.triAddr = triAddr;
+                    hit.triIndex = (uint32_t)inst.triAttributeOffset + pt_asuint(t[2].w);
+                    hit.distance = d;
+                    hitFound = true;
+                }
+            }
+        }
+    }
+    return hitFound;
+}
+
+// mul(float4(v, 0), M): row vector times matrix (Unity memory order: element (r, c) at [c*4 + r])
+inline f3 mulRow3(f3 v, const float* m)
+{
+    return V3(v.x * m[0] + v.y * m[1] + v.z * m[2] + 0.0f * m[3],
+              v.x * m[4] + v.y * m[5] + v.z * m[6] + 0.0f * m[7],
+              v.x * m[8] + v.y * m[9] + v.z * m[10] + 0.0f * m[11]);
+}
+
+// tlas.hlsl:129-234
+bool RayIntersectBvhInstance(Ctx& c, const Ray& worldRay, const PTGpuInstance& inst, bool isShadowRay, RayHit& hit, bool& stopNow)
+{
+    const SceneView& S = *c.S;
+    c.st.instanceVisits++;
+    f4 lo4 = mul44(inst.worldToLocal, f4{worldRay.origin.x, worldRay.origin.y, worldRay.origin.z, 1.0f});
+    f4 ld4 = mul44(inst.worldToLocal, f4{worldRay.direction.x, worldRay.direction.y, worldRay.direction.z, 0.0f});
+    Ray ray = {V3(lo4.x, lo4.y, lo4.z), V3(ld4.x, ld4.y, ld4.z)};          // direction is NOT re-normalised (:133-135)
+    f3 invDir = V3(1.0f / ray.direction.x, 1.0f / ray.direction.y, 1.0f / ray.direction.z);
+    uint32_t octinv4 = (7u - ((ray.direction.x < 0 ? 4u : 0u) | (ray.direction.y < 0 ? 2u : 0u) | (ray.direction.z < 0 ? 1u : 0u))) * 0x1010101u;
+    bool hitFound = false;
+    uint32_t stackX[PT_BVH_STACK_SIZE], stackY[PT_BVH_STACK_SIZE];
+    uint32_t stackPtr = 0;
+    uint32_t ngx = 0, ngy = 0x80000000u, tgx = 0, tgy = 0;
+    bool overflowed = false;
+    const uint32_t nodeOffset = (uint32_t)inst.bvhOffset;
+    while (true) {
+        if (ngy > 0x00FFFFFFu) {
+            uint32_t mask = ngy;
+            uint32_t childBitIndex = firstbithigh(mask);
+            uint32_t childNodeBaseIndex = ngx;
+            ngy &= ~(1u << childBitIndex);
+            if (ngy > 0x00FFFFFFu) {
+                if (stackPtr < PT_BVH_STACK_SIZE) { stackX[stackPtr] = ngx; stackY[stackPtr] = ngy; }
+                else overflowed = true;
+                stackPtr++;
+                if (stackPtr > c.st.maxStackDepth) c.st.maxStackDepth = stackPtr;
+            }
+            uint32_t slotIndex = (childBitIndex - 24u) ^ (octinv4 & 255u);
+            uint32_t relativeIndex = (uint32_t)__builtin_popcount(mask & ~(0xFFFFFFFFu << slotIndex));
+            uint32_t childNodeIndex = childNodeBaseIndex + relativeIndex;
+            const uint32_t* n = (const uint32_t*)(S.nodes + nodeOffset + childNodeIndex);
+            uint32_t hitmask = IntersectCWBVHNode(ray.origin, invDir, octinv4, hit.distance, n);
+            c.st.nodeVisits++;
+            ngx = n[4];
+            ngy = (hitmask & 0xFF000000u) | (n[3] >> 24);
+            tgx = n[5];
+            tgy = hitmask & 0x00FFFFFFu;
+        } else {
+            tgx = ngx; tgy = ngy;
+            ngx = 0; ngy = 0;
+        }
+        while (tgy != 0) {
+            uint32_t triangleIndex = firstbithigh(tgy);
+            uint32_t triAddr = tgx + triangleIndex * 3u;
+            hitFound = IntersectTriangleInst(c, inst, (uint32_t)inst.triOffset + triAddr, ray, hit) | hitFound;
+            tgy -= 1u << triangleIndex;
+            if (isShadowRay && c.shadowAnyHit && hitFound) { stopNow = true; goto done; }
+        }
+        if (ngy <= 0x00FFFFFFu) {
+            if (stackPtr > 0) {
+                --stackPtr;
+                if (stackPtr < PT_BVH_STACK_SIZE) { ngx = stackX[stackPtr]; ngy = stackY[stackPtr]; }
+                else { ngx = 0; ngy = 0; }
+            } else break;
+        }
+    }
+done:
+    if (overflowed) c.st.stackOverflows++;
+    if (!isShadowRay && hitFound) {
+        const PTTriangleAttributes& ta = S.attrs[hit.triIndex];
+        c.st.attrFetches++;
+        hit.intersectType = INTERSECT_TRIANGLE;
+        f3 lp = ray.origin + hit.distance * ray.direction;
+        f4 wp = mul44(inst.localToWorld, f4{lp.x, lp.y, lp.z, 1.0f});
+        hit.position = V3(wp.x, wp.y, wp.z);
+        hit.distance = length(hit.position - worldRay.origin);             // world-space length; later instances compare their LOCAL t against it (:217)
+        hit.uv = Interp2(hit.barycentric, f2{ta.uv0[0], ta.uv0[1]}, f2{ta.uv1[0], ta.uv1[1]}, f2{ta.uv2[0], ta.uv2[1]});
+        f3 normal = normalize(Interp3(hit.barycentric, V3(ta.normal0[0], ta.normal0[1], ta.normal0[2]),
+                                      V3(ta.normal1[0], ta.normal1[1], ta.normal1[2]),
+                                      V3(ta.normal2[0], ta.normal2[1], ta.normal2[2])));
+        hit.normal = normalize(mulRow3(normal, inst.worldToLocal));        // inverse-transpose (:223)
+        hit.ffnormal = dot(hit.normal, worldRay.direction) <= 0.0f ? hit.normal : -hit.normal;
+        hit.materialIndex = inst.materialIndex;
+    }
+    return hit.distance < PT_FAR_PLANE;
+}
+
+inline float selectf(float f, float t, bool c) { return c ? t : f; }          // util/common.hlsl:234-237
+
+// tlas.hlsl:236-332
+bool RayIntersectTLAS(Ctx& c, const Ray& ray, RayHit& hit, bool isShadowRay)
+{
+    const SceneView& S = *c.S;
+    if (c.opt && c.opt->rayDump && c.opt->rayDumpCount < c.opt->rayDumpCapacity) {
+        OracleRay& d = c.opt->rayDump[c.opt->rayDumpCount++];
+        d.origin[0] = ray.origin.x; d.origin[1] = ray.origin.y; d.origin[2] = ray.origin.z;
+        d.direction[0] = ray.direction.x; d.direction[1] = ray.direction.y; d.direction[2] = ray.direction.z;
+        d.tmax = hit.distance; d.kind = isShadowRay ? 1.0f : 0.0f;
+    }
+    if (c.nanRayEarlyOut && (pt_isnan(ray.origin.x) || pt_isnan(ray.origin.y) || pt_isnan(ray.origin.z) ||
+                             pt_isnan(ray.direction.x) || pt_isnan(ray.direction.y) || pt_isnan(ray.direction.z)))
+        return false;
+    f3 O = ray.origin;
+    f3 D = normalize(ray.direction);
+    f3 rD = V3(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
+    bool hitFound = false;
+    uint32_t stack[PT_BVH_STACK_SIZE];
+    uint32_t nodeIndex = 0, stackPtr = 0;
+    const float* T = S.tlas;
+    while (true) {
+        uint32_t no = nodeIndex * 16u;
+        c.st.tlasNodeVisits++;
+        uint32_t instanceCount = pt_asuint(T[no + 11]);
+        if (instanceCount == 0) {
+            f3 lmin = V3(T[no + 0], T[no + 1], T[no + 2]), lmax = V3(T[no + 4], T[no + 5], T[no + 6]);
+            f3 rmin = V3(T[no + 8], T[no + 9], T[no + 10]), rmax = V3(T[no + 12], T[no + 13], T[no + 14]);
+            uint32_t left = pt_asuint(T[no + 3]), right = pt_asuint(T[no + 7]);
+            f3 t1a = (lmin - O) * rD, t2a = (lmax - O) * rD;
+            f3 minta = V3(pt_min(t1a.x, t2a.x), pt_min(t1a.y, t2a.y), pt_min(t1a.z, t2a.z));
+            f3 maxta = V3(pt_max(t1a.x, t2a.x), pt_max(t1a.y, t2a.y), pt_max(t1a.z, t2a.z));
+            float tmina = pt_max(pt_max(pt_max(minta.x, minta.y), minta.z), 0.0f);
+            float tmaxa = pt_min(pt_min(pt_min(maxta.x, maxta.y), maxta.z), hit.distance);
+            float dist1 = selectf(tmina, PT_FAR_PLANE, tmina > tmaxa);
+            f3 t1b = (rmin - O) * rD, t2b = (rmax - O) * rD;
+            f3 mintb = V3(pt_min(t1b.x, t2b.x), pt_min(t1b.y, t2b.y), pt_min(t1b.z, t2b.z));
+            f3 maxtb = V3(pt_max(t1b.x, t2b.x), pt_max(t1b.y, t2b.y), pt_max(t1b.z, t2b.z));
+            float tminb = pt_max(pt_max(pt_max(mintb.x, mintb.y), mintb.z), 0.0f);
+            float tmaxb = pt_min(pt_min(pt_min(maxtb.x, maxtb.y), maxtb.z), hit.distance);
+            float dist2 = selectf(tminb, PT_FAR_PLANE, tminb > tmaxb);
+            if (dist1 > dist2) {
+                float h = dist1; dist1 = dist2; dist2 = h;
+                uint32_t t = left; left = right; right = t;
+            }
+            if (dist1 == PT_FAR_PLANE) {
+                if (stackPtr > 0) nodeIndex = stack[--stackPtr];
+                else break;
+            } else {
+                nodeIndex = left;
+                if (dist2 != PT_FAR_PLANE) {
+                    if (stackPtr < PT_BVH_STACK_SIZE) stack[stackPtr] = right;
+                    stackPtr++;
+                }
+            }
+        }
+        if (instanceCount > 0) {
+            uint32_t firstInstance = pt_asuint(T[no + 15]);
+            for (uint32_t i = 0; i < instanceCount; ++i) {
+                uint32_t instanceIndex = pt_asuint(T[S.tlasIndexOffset + firstInstance + i]);
+                bool stopNow = false;
+                hitFound = RayIntersectBvhInstance(c, ray, S.instances[instanceIndex], isShadowRay, hit, stopNow) | hitFound;
+                if (stopNow) return true;
+            }
+            if (stackPtr > 0) nodeIndex = stack[--stackPtr];
+            else break;
+        }
+    }
+    return hitFound;
+}
+
+// ------------------------------------------------------------------------------------------
 // util/intersect.hlsl
 // ------------------------------------------------------------------------------------------
 inline float RectIntersect(f3 pos, f3 u, f3 v, f4 plane, const Ray& r)            // :6-27
@@ -378,7 +575,8 @@ inline bool RayIntersect(Ctx& c, const Ray& ray, RayHit& hit)                   
 {
     hit.distance = PT_FAR_PLANE;
     c.st.closestHitRays++;
-    RayIntersectBvh(c, ray, hit, false);
+    if (c.S->hasTlas) RayIntersectTLAS(c, ray, hit, false);                     // util/tlas.hlsl:334-344
+    else RayIntersectBvh(c, ray, hit, false);
     IntersectLights(c, ray, hit);
     return hit.distance < PT_FAR_PLANE;
 }
@@ -389,6 +587,7 @@ inline bool ShadowRayIntersect(Ctx& c, const Ray& ray)                          
     memset(&hit, 0, sizeof(hit));
     hit.distance = PT_FAR_PLANE;
     c.st.shadowRays++;
+    if (c.S->hasTlas) return RayIntersectTLAS(c, ray, hit, true);               // util/tlas.hlsl:346-352
     return RayIntersectBvh(c, ray, hit, true);
 }
 
@@ -1075,6 +1274,9 @@ SceneView MakeView(const PTSceneDesc* s)
     v.tex = s->textureData; v.texUints = s->textureDataUints;
     v.hasLights = (s->features & PT_FEATURE_HAS_LIGHTS) && s->lightCount > 0;
     v.hasTextures = (s->features & PT_FEATURE_HAS_TEXTURES) && s->textureDataUints > 0;
+    v.hasTlas = (s->features & PT_FEATURE_HAS_TLAS) != 0;
+    v.tlas = s->tlasData; v.tlasFloats = s->tlasDataFloats; v.tlasIndexOffset = s->tlasIndexOffset;
+    v.instances = (const PTGpuInstance*)s->gpuInstances; v.instanceCount = s->instanceCount;
     return v;
 }
 

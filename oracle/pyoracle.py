@@ -164,7 +164,7 @@ def load_ref_tinybvh():
 class SceneBuffers:
     """Keeps the numpy arrays alive behind a PTSceneDesc."""
 
-    def __init__(self, scene, nodes, tris):
+    def __init__(self, scene, nodes, tris, tlas_data=None, tlas_index_offset=0, gpu_instances=None):
         self.scene = scene
         self.nodes = np.ascontiguousarray(nodes).view(np.uint8)
         self.tris = np.ascontiguousarray(tris).view(np.uint8)
@@ -186,7 +186,21 @@ class SceneBuffers:
         d.textureData = self.tex.ctypes.data if self.tex.size else None
         d.textureDataUints = self.tex.size
         d.features = scene.features
+        if tlas_data is not None:
+            self.tlas = np.ascontiguousarray(tlas_data, dtype=np.float32)
+            self.inst = np.ascontiguousarray(gpu_instances)
+            d.tlasData = self.tlas.ctypes.data
+            d.tlasDataFloats = self.tlas.size
+            d.tlasIndexOffset = tlas_index_offset
+            d.instanceCount = self.inst.shape[0]
+            d.gpuInstances = self.inst.ctypes.data
         self.desc = d
+
+
+def buffers_from_bvhscene(bvh_scene):
+    """SceneBuffers for the oracle from the arrays the product-side BVHScene mirror assembled (plain data hand-over)."""
+    return SceneBuffers(bvh_scene.scene, bvh_scene.bvh_nodes, bvh_scene.bvh_tris, bvh_scene.tlas_data,
+                        bvh_scene.tlas_index_offset, bvh_scene.gpu_instances)
 
 
 def render(buffers: SceneBuffers, params, accumulated=None, threads=None, window=None, shadow_any_hit=False,

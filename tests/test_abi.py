@@ -59,7 +59,7 @@ def test_struct_sizes_match_c_headers():
         sizes = [int(x) for x in subprocess.check_output([exe]).split()]
     assert sizes[0] == C.sizeof(abi.PTSceneDesc)
     assert sizes[1] == C.sizeof(abi.PTFrameParams)
-    assert sizes[2] == C.sizeof(abi.PTStats) == 14 * 8
+    assert sizes[2] == C.sizeof(abi.PTStats) == 16 * 8
     assert sizes[3] == C.sizeof(abi.PTTimings)
     assert sizes[4:] == [80, 48, 128, 128, 64, 64, 192, 144]
     assert abi.CWBVH_NODE.itemsize == 80 and abi.TRI_ATTR.itemsize == 128 and abi.BLAS_INSTANCE.itemsize == 192

@@ -16,7 +16,7 @@ LINF_TOL = 1e-4
 
 
 def _oracle_frame(oracle, pt, p, accumulated=None, **kw):
-    b = oracle.SceneBuffers(pt.scene, pt._bvhScene.bvh_nodes, pt._bvhScene.bvh_tris)
+    b = oracle.buffers_from_bvhscene(pt._bvhScene)
     return oracle.render(b, p, accumulated=accumulated, **kw)
 
 
@@ -39,7 +39,7 @@ def _stats_equal(gpu_stats, ref_stats, fields):
 
 ALL_COUNTERS = ["paths", "closestHitRays", "shadowRays", "nodeVisits", "triTests", "attrFetches", "materialFetches",
                 "lightFetches", "texelFetches", "texDescriptorFetches", "pixelsWritten", "pixelsRead", "maxStackDepth",
-                "stackOverflows"]
+                "stackOverflows", "tlasNodeVisits", "instanceVisits"]
 
 
 SCHEDULES = [0, 1, 2, 3]    # 0 megakernel, 1 wavefront + refill trace, 2 wavefront one ray per lane, 3 wavefront + persistent dynamic-chunk trace
@@ -255,3 +255,38 @@ def test_plain_c_host(tmp_path, oracle):
         ref, _ = oracle.render(b, p, accumulated=ref)
     # the C host computes its camera matrices in fp32 C arithmetic, the Python host in fp64 numpy: allow that difference
     assert np.abs(gpu - ref).mean() < 0.05 and gpu.shape == ref.shape and np.isfinite(gpu).all()
+
+
+@pytest.mark.parametrize("schedule", SCHEDULES)
+def test_tlas_instanced_scene(oracle, schedule):
+    """HAS_TLAS (util/tlas.hlsl): 15 instances of 4 meshes, rotations and non-uniform scales, two-level traversal.
+    Frame and every counter (TLAS nodes, instance visits included) equal the oracle's."""
+    s = scenes.instanced_scene()
+    pt = PathTracer(s, width=144, height=96, samplesPerPass=3, schedule=schedule)
+    pt.set_stats_level(1)
+    p = pt.params(seed=0x7EA5)
+    pt.render_pass(p)
+    gpu = pt.readback()
+    ref, st = _oracle_frame(oracle, pt, p, shadow_any_hit=True)
+    _, nbad = _compare(gpu, ref, f"instanced (HAS_TLAS), schedule {schedule}")
+    assert nbad == 0
+    _stats_equal(pt.stats(), st, ALL_COUNTERS)
+    assert st.tlasNodeVisits > 0 and st.instanceVisits > 0
+    pt.close()
+
+
+def test_tlas_progressive_and_cleanup(oracle):
+    s = scenes.instanced_scene(count=9, detail=8)
+    pt = PathTracer(s, width=96, height=64, samplesPerPass=2, schedule=1)
+    pt.set_wavefront_iterations(3)
+    seeds = [11, 22, 33]
+    params, ref = [], None
+    for k in range(3):
+        params.append(pt.params(seeds[k]))
+        pt.OnRenderImage(seeds[k])
+    gpu = pt.readback()
+    for p in params:
+        ref, _ = _oracle_frame(oracle, pt, p, accumulated=ref)
+    _, nbad = _compare(gpu, ref, "instanced, 3 pipelined passes, cleanup kernel")
+    assert nbad == 0
+    pt.close()

@@ -38,6 +38,12 @@ TLAS_NODE = np.dtype([
 ])
 assert TLAS_NODE.itemsize == 64
 
+GPU_INSTANCE = np.dtype([
+    ("localToWorld", "<f4", 16), ("worldToLocal", "<f4", 16),
+    ("bvhOffset", "<i4"), ("triOffset", "<i4"), ("triAttributeOffset", "<i4"), ("materialIndex", "<i4"),
+])
+assert GPU_INSTANCE.itemsize == 144
+
 BLAS_INSTANCE = np.dtype([
     ("localToWorld", "<f4", 16), ("worldToLocal", "<f4", 16),
     ("aabbMin", "<f4", 3), ("blasIndex", "<u4"), ("aabbMax", "<f4", 3), ("mask", "<u4"),
@@ -66,6 +72,9 @@ class PTSceneDesc(C.Structure):
         ("lights", C.c_void_p), ("lightCount", C.c_uint32), ("_pad1", C.c_uint32),
         ("textureData", C.c_void_p), ("textureDataUints", C.c_uint64),
         ("features", C.c_uint32), ("_pad2", C.c_uint32),
+        ("tlasData", C.c_void_p), ("tlasDataFloats", C.c_uint64),
+        ("tlasIndexOffset", C.c_uint32), ("instanceCount", C.c_uint32),
+        ("gpuInstances", C.c_void_p),
     ]
 
 
@@ -102,7 +111,7 @@ class PTStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "paths", "closestHitRays", "shadowRays", "nodeVisits", "triTests", "attrFetches",
         "materialFetches", "lightFetches", "texelFetches", "texDescriptorFetches",
-        "pixelsWritten", "pixelsRead", "maxStackDepth", "stackOverflows")]
+        "pixelsWritten", "pixelsRead", "maxStackDepth", "stackOverflows", "tlasNodeVisits", "instanceVisits")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -115,7 +124,8 @@ class PTStats(C.Structure):
         """bytes the reference kernel reads/writes for this work."""
         return int(80 * self.nodeVisits + 48 * self.triTests + 128 * self.attrFetches
                    + 128 * self.materialFetches + 64 * self.lightFetches + 4 * self.texelFetches
-                   + 16 * self.texDescriptorFetches + 16 * (self.pixelsWritten + self.pixelsRead))
+                   + 16 * self.texDescriptorFetches + 16 * (self.pixelsWritten + self.pixelsRead)
+                   + 64 * self.tlasNodeVisits + 144 * self.instanceVisits)
 
 
 class PTTimings(C.Structure):

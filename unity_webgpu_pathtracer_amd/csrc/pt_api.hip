@@ -41,7 +41,7 @@ struct EventPair { hipEvent_t start, stop; uint32_t launches; };
 struct PTContext {
     int device = 0;
     hipStream_t stream = nullptr;
-    DeviceBuffer nodes, tris, attrs, materials, lights, tex;
+    DeviceBuffer nodes, tris, attrs, materials, lights, tex, tlas, instances;
     DScene scene = {};
     bool hasScene = false;
     float4* frames[2] = {nullptr, nullptr};
@@ -108,7 +108,7 @@ int ensure_wavefront(PTContext* c, PTContext::WfSet& set, uint32_t numSlots, uin
     const size_t n = numSlots;
     const uint32_t numRows = 4u * (numSlots >> 6);
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    size_t total = align(n * 4) * 2 + align(n * 16) * 12 + align(n * 2) + align((size_t)maxIterations * 4) +
+    size_t total = align(n * 4) * 2 + align(n * 16) * 13 + align(n * 2) + align((size_t)maxIterations * 4) +
                    align((size_t)numRows * 16 * 8) + align(8 * 32 * 4);
     if (set.arena && set.arenaBytes < total) { hipFree(set.arena); set.arena = nullptr; set.arenaBytes = 0; }
     if (!set.arena) {
@@ -120,7 +120,7 @@ int ensure_wavefront(PTContext* c, PTContext::WfSet& set, uint32_t numSlots, uin
     PTWfBuffers& B = set.wf;
     B.flags = (uint32_t*)carve(n * 4);
     B.rng = (uint32_t*)carve(n * 4);
-    float4** arrs[12] = {&B.ro, &B.rd, &B.rad, &B.thr, &B.color, &B.neeO, &B.envD, &B.lightD, &B.envC, &B.lightC, &B.pthr, &B.hit};
+    float4** arrs[13] = {&B.ro, &B.rd, &B.rad, &B.thr, &B.color, &B.neeO, &B.envD, &B.lightD, &B.envC, &B.lightC, &B.pthr, &B.hit, &B.hit2};
     for (auto a : arrs) *a = (float4*)carve(n * 16);
     B.occl = (uint8_t*)carve(n * 2);
     B.aliveFlags = (uint32_t*)carve((size_t)maxIterations * 4);
@@ -260,7 +260,7 @@ PT_API int PTDestroy(PTContext* c)
     if (!c) return PT_OK;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
-    for (auto* b : {&c->nodes, &c->tris, &c->attrs, &c->materials, &c->lights, &c->tex}) if (b->ptr) hipFree(b->ptr);
+    for (auto* b : {&c->nodes, &c->tris, &c->attrs, &c->materials, &c->lights, &c->tex, &c->tlas, &c->instances}) if (b->ptr) hipFree(b->ptr);
     for (int i = 0; i < 2; i++) if (c->frames[i]) hipFree(c->frames[i]);
     if (c->dStats) hipFree(c->dStats);
     for (auto& set : c->sets) {
@@ -279,7 +279,10 @@ PT_API int PTDestroy(PTContext* c)
 PT_API int PTSetScene(PTContext* c, const PTSceneDesc* s)
 {
     if (!c || !s) return fail(PT_ERR_INVALID_ARG, "ctx/scene == NULL");
-    if (s->features & PT_FEATURE_HAS_TLAS) return fail(PT_ERR_UNSUPPORTED, "HAS_TLAS is not implemented (SURVEY.md 8f N1)");
+    const bool tlasOn = (s->features & PT_FEATURE_HAS_TLAS) != 0;
+    if (tlasOn && (!s->tlasData || s->tlasDataFloats < 16 || !s->gpuInstances || s->instanceCount == 0 ||
+                   s->tlasIndexOffset >= s->tlasDataFloats || s->tlasIndexOffset % 16 != 0))
+        return fail(PT_ERR_INVALID_ARG, "HAS_TLAS needs tlasData (nodes + indices), tlasIndexOffset and gpuInstances");
     if (!s->bvhNodes || s->bvhNodesBytes < 80 || s->bvhNodesBytes % 80) return fail(PT_ERR_INVALID_ARG, "bvhNodes must be a non-empty multiple of 80 bytes");
     if (!s->bvhTris || s->bvhTrisBytes % 48) return fail(PT_ERR_INVALID_ARG, "bvhTris must be a multiple of 48 bytes");
     if (!s->triAttrs || s->triAttrsBytes % 128) return fail(PT_ERR_INVALID_ARG, "triAttrs must be a multiple of 128 bytes");
@@ -298,6 +301,8 @@ PT_API int PTSetScene(PTContext* c, const PTSceneDesc* s)
     const bool textures = (s->features & PT_FEATURE_HAS_TEXTURES) != 0;
     if (lights && (rc = upload(c, c->lights, s->lights, (size_t)s->lightCount * 64))) return rc;
     if (textures && (rc = upload(c, c->tex, s->textureData, (size_t)s->textureDataUints * 4))) return rc;
+    if (tlasOn && (rc = upload(c, c->tlas, s->tlasData, (size_t)s->tlasDataFloats * 4))) return rc;
+    if (tlasOn && (rc = upload(c, c->instances, s->gpuInstances, (size_t)s->instanceCount * 144))) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));      // inputs are borrowed for the duration of the call only
     c->scene.nodes = (const uint4*)c->nodes.ptr;
     c->scene.tris = (const float4*)c->tris.ptr;
@@ -309,6 +314,10 @@ PT_API int PTSetScene(PTContext* c, const PTSceneDesc* s)
     c->scene.materialCount = s->materialCount;
     c->scene.hasLights = lights ? 1u : 0u;
     c->scene.hasTextures = textures ? 1u : 0u;
+    c->scene.tlas = tlasOn ? (const float*)c->tlas.ptr : nullptr;
+    c->scene.instances = tlasOn ? (const float4*)c->instances.ptr : nullptr;
+    c->scene.tlasIndexOffset = tlasOn ? s->tlasIndexOffset : 0u;
+    c->scene.hasTlas = tlasOn ? 1u : 0u;
     c->hasScene = true;
     return PT_OK;
 }
@@ -382,7 +391,7 @@ PT_API int PTGetStats(PTContext* c, PTStats* out)
     unsigned long long h[16];
     HIP_TRY(hipMemcpyAsync(h, c->dStats, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    static_assert(sizeof(PTStats) == 14 * 8, "PTStats is 14 counters");
+    static_assert(sizeof(PTStats) == 16 * 8, "PTStats is 16 counters");
     memcpy(out, h, sizeof(PTStats));
     return PT_OK;
 }

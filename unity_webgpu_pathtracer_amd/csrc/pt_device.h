@@ -87,11 +87,17 @@ struct DScene {
     uint32_t materialCount;
     uint32_t hasLights;
     uint32_t hasTextures;
+    // HAS_TLAS (util/tlas.hlsl): TLASData floats, instance records as 9 x float4 (PTGpuInstance)
+    const float*  tlas;
+    const float4* instances;
+    uint32_t tlasIndexOffset;
+    uint32_t hasTlas;
 };
 
 struct Counters {
     uint32_t paths, closestRays, shadowRays, nodeVisits, triTests, attrFetches, materialFetches,
-             lightFetches, texelFetches, texDescFetches, pixelsWritten, pixelsRead, maxStack, overflows;
+             lightFetches, texelFetches, texDescFetches, pixelsWritten, pixelsRead, maxStack, overflows,
+             tlasNodeVisits, instanceVisits;
 };
 
 PT_DEV float rnd(uint32_t& s) { return pt_random_float(&s); }
@@ -280,6 +286,182 @@ PT_DEV void traverse_cwbvh(const DScene& S, v3 o, v3 d, bool anyHit, TraceHit& h
 }
 
 // ------------------------------------------------------------------------------------------
+// HAS_TLAS variant.  util/tlas.hlsl:22-59, 129-332: a 2-wide TLAS over instances, each instance a CWBVH walked in the
+// instance's LOCAL space (direction not re-normalised).  Reference quirks kept: triangles accept distance > 0 (not
+// 1e-4); after an instance produced a hit, hit.distance becomes the WORLD-space length and later instances compare
+// their local parameters against it; the attribute record is fetched once per instance that improved the hit.
+// ------------------------------------------------------------------------------------------
+struct HitRecord {
+    TraceHit h;          // t, u, v, triIndex
+    v3 pos;              // HAS_TLAS: world-space hit position (tlas.hlsl:216)
+    uint32_t inst;       // HAS_TLAS: instance that owns the hit
+};
+
+PT_DEV v4 mul44c(float4 c0, float4 c1, float4 c2, float4 c3, v4 v)   // Matrix4x4 given as its four columns
+{
+    v4 r;
+    r.x = c0.x * v.x + c1.x * v.y + c2.x * v.z + c3.x * v.w;
+    r.y = c0.y * v.x + c1.y * v.y + c2.y * v.z + c3.y * v.w;
+    r.z = c0.z * v.x + c1.z * v.y + c2.z * v.z + c3.z * v.w;
+    r.w = c0.w * v.x + c1.w * v.y + c2.w * v.z + c3.w * v.w;
+    return r;
+}
+
+PT_DEV bool intersect_triangle_inst(const float4* __restrict__ tris, uint32_t triAddr, uint32_t attrOffset, v3 o, v3 d, TraceHit& hit)
+{
+    float4 t0 = tris[triAddr + 0], t1 = tris[triAddr + 1], t2 = tris[triAddr + 2];
+    asm volatile("" : "+v"(t0.x), "+v"(t1.x), "+v"(t2.x), "+v"(t2.w));
+    v3 e2 = mk3(t0.x, t0.y, t0.z), e1 = mk3(t1.x, t1.y, t1.z), v0 = mk3(t2.x, t2.y, t2.z);
+    bool found = false;
+    v3 r = cross3(d, e2);
+    float a = dot3(e1, r);
+    if (pt_abs(a) > 0.0000001f) {
+        float f = 1.0f / a;
+        v3 s = o - v0;
+        float u = f * dot3(s, r);
+        if (u >= 0.0f && u <= 1.0f) {
+            v3 q = cross3(s, e1);
+            float v = f * dot3(d, q);
+            if (v >= 0.0f && u + v <= 1.0f) {
+                float dist = f * dot3(e2, q);
+                if (dist > 0.0f && dist < hit.t) {
+                    hit.u = u; hit.v = v;
+                    hit.triIndex = attrOffset + pt_asuint(t2.w);
+                    hit.t = dist;
+                    found = true;
+                }
+            }
+        }
+    }
+    return found;
+}
+
+// tlas.hlsl:129-234 for one instance.  Returns hit.distance < FAR_PLANE; sets stopNow for an occluded shadow ray.
+template <bool STATS, class ST>
+PT_DEV bool traverse_instance(const DScene& S, v3 wo, v3 wd, uint32_t instIndex, bool isShadow, HitRecord& rec, ST& st, Counters& cn,
+                              bool& stopNow)
+{
+    const float4* ip = S.instances + (size_t)instIndex * 9;
+    const float4 w0 = ip[4], w1 = ip[5], w2 = ip[6], w3 = ip[7], ints = ip[8];
+    if (STATS) cn.instanceVisits++;
+    const uint32_t nodeOffset = pt_asuint(ints.x), triOffset = pt_asuint(ints.y), attrOffset = pt_asuint(ints.z);
+    v4 lo4 = mul44c(w0, w1, w2, w3, v4{wo.x, wo.y, wo.z, 1.0f});
+    v4 ld4 = mul44c(w0, w1, w2, w3, v4{wd.x, wd.y, wd.z, 0.0f});
+    const v3 o = mk3(lo4.x, lo4.y, lo4.z), d = mk3(ld4.x, ld4.y, ld4.z);
+    v3 invDir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    uint32_t octinv4 = (7u - ((d.x < 0.0f ? 4u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 1u : 0u))) * 0x1010101u;
+    bool hitFound = false, overflow = false;
+    uint32_t sp = 0;
+    uint2 ng = make_uint2(0u, 0x80000000u), tg = make_uint2(0u, 0u);
+    while (true) {
+        if (ng.y > 0x00FFFFFFu) {
+            uint32_t mask = ng.y;
+            uint32_t childBitIndex = 31u - (uint32_t)__clz((int)mask);
+            uint32_t childNodeBaseIndex = ng.x;
+            ng.y &= ~(1u << childBitIndex);
+            if (ng.y > 0x00FFFFFFu) {
+                stack_push(st, sp, ng);
+                if (sp >= PT_BVH_STACK_SIZE) overflow = true;
+                sp++;
+                if (STATS) cn.maxStack = sp > cn.maxStack ? sp : cn.maxStack;
+            }
+            uint32_t slotIndex = (childBitIndex - 24u) ^ (octinv4 & 255u);
+            uint32_t relativeIndex = (uint32_t)__popc(mask & ~(0xFFFFFFFFu << slotIndex));
+            const uint4* np = S.nodes + (size_t)(nodeOffset + childNodeBaseIndex + relativeIndex) * 5;
+            uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+            uint32_t hitmask = cwbvh_node_hitmask(o, invDir, octinv4, rec.h.t, n0, n1, n2, n3, n4);
+            if (STATS) cn.nodeVisits++;
+            ng.x = n1.x;
+            ng.y = (hitmask & 0xFF000000u) | (n0.w >> 24);
+            tg.x = n1.y;
+            tg.y = hitmask & 0x00FFFFFFu;
+        } else {
+            tg = ng;
+            ng = make_uint2(0u, 0u);
+        }
+        while (tg.y != 0u) {
+            uint32_t triangleIndex = 31u - (uint32_t)__clz((int)tg.y);
+            uint32_t triAddr = tg.x + triangleIndex * 3u;
+            hitFound = intersect_triangle_inst(S.tris, triOffset + triAddr, attrOffset, o, d, rec.h) | hitFound;
+            if (STATS) cn.triTests++;
+            tg.y -= 1u << triangleIndex;
+            if (isShadow && hitFound) { stopNow = true; tg.y = 0u; ng.y = 0u; sp = 0u; }
+        }
+        if (ng.y <= 0x00FFFFFFu) {
+            if (sp > 0u) { --sp; ng = stack_pop(st, sp); }
+            else break;
+        }
+    }
+    if (STATS && overflow) cn.overflows++;
+    if (!isShadow && hitFound) {
+        if (STATS) cn.attrFetches++;
+        const float4 l0 = ip[0], l1 = ip[1], l2 = ip[2], l3 = ip[3];
+        v3 lp = o + rec.h.t * d;
+        v4 wp = mul44c(l0, l1, l2, l3, v4{lp.x, lp.y, lp.z, 1.0f});
+        rec.pos = mk3(wp.x, wp.y, wp.z);
+        rec.h.t = length3(rec.pos - wo);
+        rec.inst = instIndex;
+    }
+    return rec.h.t < PT_FAR_PLANE;
+}
+
+// tlas.hlsl:236-332
+template <bool STATS, class ST>
+PT_DEV bool traverse_tlas(const DScene& S, v3 O, v3 dir, bool isShadow, HitRecord& rec, ST& st, Counters& cn)
+{
+    if (pt_isnan(O.x) || pt_isnan(O.y) || pt_isnan(O.z) || pt_isnan(dir.x) || pt_isnan(dir.y) || pt_isnan(dir.z)) return false;
+    const v3 D = normalize3(dir);
+    const v3 rD = mk3(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
+    bool hitFound = false;
+    uint32_t stack[PT_BVH_STACK_SIZE];
+    uint32_t nodeIndex = 0u, sp = 0u;
+    const float* T = S.tlas;
+    while (true) {
+        const float4* np = (const float4*)(T + (size_t)nodeIndex * 16u);
+        const float4 a = np[0], b = np[1], c = np[2], e = np[3];
+        if (STATS) cn.tlasNodeVisits++;
+        const uint32_t instanceCount = pt_asuint(c.w);
+        if (instanceCount == 0u) {
+            uint32_t left = pt_asuint(a.w), right = pt_asuint(b.w);
+            v3 t1a = (mk3(a.x, a.y, a.z) - O) * rD, t2a = (mk3(b.x, b.y, b.z) - O) * rD;
+            float tmina = pt_max(pt_max(pt_max(pt_min(t1a.x, t2a.x), pt_min(t1a.y, t2a.y)), pt_min(t1a.z, t2a.z)), 0.0f);
+            float tmaxa = pt_min(pt_min(pt_min(pt_max(t1a.x, t2a.x), pt_max(t1a.y, t2a.y)), pt_max(t1a.z, t2a.z)), rec.h.t);
+            float dist1 = tmina > tmaxa ? PT_FAR_PLANE : tmina;
+            v3 t1b = (mk3(c.x, c.y, c.z) - O) * rD, t2b = (mk3(e.x, e.y, e.z) - O) * rD;
+            float tminb = pt_max(pt_max(pt_max(pt_min(t1b.x, t2b.x), pt_min(t1b.y, t2b.y)), pt_min(t1b.z, t2b.z)), 0.0f);
+            float tmaxb = pt_min(pt_min(pt_min(pt_max(t1b.x, t2b.x), pt_max(t1b.y, t2b.y)), pt_max(t1b.z, t2b.z)), rec.h.t);
+            float dist2 = tminb > tmaxb ? PT_FAR_PLANE : tminb;
+            if (dist1 > dist2) {
+                float h = dist1; dist1 = dist2; dist2 = h;
+                uint32_t t = left; left = right; right = t;
+            }
+            if (dist1 == PT_FAR_PLANE) {
+                if (sp > 0u) nodeIndex = stack[--sp];
+                else break;
+            } else {
+                nodeIndex = left;
+                if (dist2 != PT_FAR_PLANE) {
+                    if (sp < PT_BVH_STACK_SIZE) stack[sp] = right;
+                    sp++;
+                }
+            }
+        }
+        if (instanceCount > 0u) {
+            const uint32_t firstInstance = pt_asuint(e.w);
+            for (uint32_t i = 0; i < instanceCount; ++i) {
+                const uint32_t instanceIndex = pt_asuint(T[S.tlasIndexOffset + firstInstance + i]);
+                bool stopNow = false;
+                hitFound = traverse_instance<STATS>(S, O, dir, instanceIndex, isShadow, rec, st, cn, stopNow) | hitFound;
+                if (stopNow) return true;
+            }
+            if (sp > 0u) nodeIndex = stack[--sp];
+            else break;
+        }
+    }
+    return hitFound;
+}
+
+// ------------------------------------------------------------------------------------------
 // surface hit record (util/common.hlsl:173-193) and hit attribute fetch (util/bvh.hlsl:201-212)
 // ------------------------------------------------------------------------------------------
 struct SurfHit {
@@ -310,6 +492,30 @@ PT_DEV void fetch_hit_attributes(const DScene& S, v3 o, v3 d, const TraceHit& th
     hit.uv.x = uv01.x * w + uv01.z * th.u + uv2m.x * th.v;
     hit.uv.y = uv01.y * w + uv01.w * th.u + uv2m.y * th.v;
     hit.materialIndex = (int32_t)pt_asuint(uv2m.z);
+    hit.isLight = 0u;
+}
+
+// tlas.hlsl:208-229 for the instance that owns the final hit (the per-instance fetches were counted during traversal)
+PT_DEV void fetch_hit_attributes_tlas(const DScene& S, v3 d, const HitRecord& rec, SurfHit& hit)
+{
+    const float4* a = S.attrs + (size_t)rec.h.triIndex * 8;
+    float4 n0 = a[0], n1 = a[1], n2 = a[2], uv01 = a[6], uv2m = a[7];
+    const float4* ip = S.instances + (size_t)rec.inst * 9;
+    const float4 w0 = ip[4], w1 = ip[5], w2 = ip[6], ints = ip[8];
+    hit.distance = rec.h.t;
+    hit.triIndex = rec.h.triIndex;
+    hit.position = rec.pos;
+    float w = 1.0f - rec.h.u - rec.h.v;
+    hit.uv.x = uv01.x * w + uv01.z * rec.h.u + uv2m.x * rec.h.v;
+    hit.uv.y = uv01.y * w + uv01.w * rec.h.u + uv2m.y * rec.h.v;
+    v3 n = normalize3(interp3(rec.h.u, rec.h.v, mk3(n0.x, n0.y, n0.z), mk3(n1.x, n1.y, n1.z), mk3(n2.x, n2.y, n2.z)));
+    // mul(float4(normal, 0), worldToLocal): row vector times matrix = dot with each column
+    v3 wn = mk3(n.x * w0.x + n.y * w0.y + n.z * w0.z + 0.0f * w0.w,
+                n.x * w1.x + n.y * w1.y + n.z * w1.z + 0.0f * w1.w,
+                n.x * w2.x + n.y * w2.y + n.z * w2.z + 0.0f * w2.w);
+    hit.normal = normalize3(wn);
+    hit.ffnormal = dot3(hit.normal, d) <= 0.0f ? hit.normal : -hit.normal;
+    hit.materialIndex = (int32_t)pt_asuint(ints.w);
     hit.isLight = 0u;
 }
 
@@ -994,7 +1200,7 @@ PT_DEV void path_init(const PTFrameParams& P, uint32_t pixelX, uint32_t pixelY, 
 // kernel does.  Without it the pixel's sample sum stays in r.color and a separate resolve step applies the same formula
 // later (pt_wavefront.hip), which lets consecutive passes overlap.
 template <bool STATS, bool INLINE_RESOLVE = true>
-PT_DEV void path_step(const DScene& S, const PTFrameParams& P, PathRegs& r, const TraceHit& ch, bool occEnv, bool occLight,
+PT_DEV void path_step(const DScene& S, const PTFrameParams& P, PathRegs& r, const HitRecord& rec, bool occEnv, bool occLight,
                       uint32_t pixelX, uint32_t pixelY, uint32_t pixelIndex,
                       const float4* __restrict__ accumulated, float4* __restrict__ output, Counters& cn)
 {
@@ -1019,7 +1225,10 @@ PT_DEV void path_step(const DScene& S, const PTFrameParams& P, PathRegs& r, cons
         hit.materialIndex = 0;
         hit.position = mk3(0.0f); hit.normal = mk3(0.0f); hit.ffnormal = mk3(0.0f);
         hit.uv = {0.0f, 0.0f};
-        if (ch.t < PT_FAR_PLANE) fetch_hit_attributes<STATS>(S, r.ro, r.rd, ch, hit, cn);
+        if (rec.h.t < PT_FAR_PLANE) {
+            if (S.hasTlas) fetch_hit_attributes_tlas(S, r.rd, rec, hit);
+            else fetch_hit_attributes<STATS>(S, r.ro, r.rd, rec.h, hit, cn);
+        }
         intersect_lights<STATS>(S, r.ro, r.rd, hit, cn);
 
         if (!(hit.distance < PT_FAR_PLANE)) {
@@ -1128,12 +1337,13 @@ PT_DEV uint32_t wave_max_u32(uint32_t v)
     for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
     return v;
 }
-#define PT_NUM_COUNTERS 14
+#define PT_NUM_COUNTERS 16
 PT_DEV void counters_to_array(const Counters& cn, uint32_t* vals)
 {
     vals[0] = cn.paths; vals[1] = cn.closestRays; vals[2] = cn.shadowRays; vals[3] = cn.nodeVisits; vals[4] = cn.triTests;
     vals[5] = cn.attrFetches; vals[6] = cn.materialFetches; vals[7] = cn.lightFetches; vals[8] = cn.texelFetches;
     vals[9] = cn.texDescFetches; vals[10] = cn.pixelsWritten; vals[11] = cn.pixelsRead; vals[12] = cn.maxStack; vals[13] = cn.overflows;
+    vals[14] = cn.tlasNodeVisits; vals[15] = cn.instanceVisits;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1166,10 +1376,18 @@ PT_DEV bool ray_begin(RayState& r, v3 o, v3 d, bool anyHit)
 }
 
 // one outer iteration; returns true when the traversal is complete
+#ifdef PT_TRACE_DIAG
+#define PT_DIAG_WAVE_COUNT(field) do { if ((int)(threadIdx.x & 63u) == __ffsll((long long)__ballot(true)) - 1) cn.field++; } while (0)
+#else
+#define PT_DIAG_WAVE_COUNT(field) do { } while (0)
+#endif
+
 template <bool STATS, class ST>
 PT_DEV bool ray_step(const DScene& S, RayState& r, ST& st, Counters& cn)
 {
+    PT_DIAG_WAVE_COUNT(attrFetches);          // wave-level outer iterations
     if (r.ng.y > 0x00FFFFFFu) {
+        PT_DIAG_WAVE_COUNT(materialFetches);  // wave-level node-block executions
         uint32_t mask = r.ng.y;
         uint32_t childBitIndex = 31u - (uint32_t)__clz((int)mask);
         uint32_t childNodeBaseIndex = r.ng.x;
@@ -1191,11 +1409,24 @@ PT_DEV bool ray_step(const DScene& S, RayState& r, ST& st, Counters& cn)
         r.ng.y = (hitmask & 0xFF000000u) | (n0.w >> 24);
         r.tg.x = n1.y;
         r.tg.y = hitmask & 0x00FFFFFFu;
+#ifdef PT_PREFETCH_NEXT_NODE
+        // triangles will be tested before the next node is needed: start pulling that node towards the CU now
+        if (r.tg.y != 0u && r.ng.y > 0x00FFFFFFu) {
+            const uint32_t m = r.ng.y;
+            const uint32_t cbi = 31u - (uint32_t)__clz((int)m);
+            const uint32_t sl = (cbi - 24u) ^ (r.octinv4 & 255u);
+            const uint32_t nxt = r.ng.x + (uint32_t)__popc(m & ~(0xFFFFFFFFu << sl));
+            const uint32_t* pp = (const uint32_t*)(S.nodes + (size_t)nxt * 5);
+            uint32_t a = pp[0], b = pp[19];
+            asm volatile("" :: "v"(a), "v"(b));
+        }
+#endif
     } else {
         r.tg = r.ng;
         r.ng = make_uint2(0u, 0u);
     }
     while (r.tg.y != 0u) {
+        PT_DIAG_WAVE_COUNT(lightFetches);     // wave-level triangle-block executions
         uint32_t triangleIndex = 31u - (uint32_t)__clz((int)r.tg.y);
         uint32_t triAddr = r.tg.x + triangleIndex * 3u;
         intersect_triangle(S.tris, triAddr, r.o, r.d, r.hit);
@@ -1268,4 +1499,62 @@ PT_DEV bool ray_microstep(const DScene& S, RayState& r, ST& st, Counters& cn)
         }
     }
     return finished;
+}
+
+// The two halves of ray_microstep as separate phases, so that a wave can decide per iteration WHICH phase to run:
+// triangle tests are short and sparse (measured: the nested triangle loop executed at 8 % lane utilisation and cost
+// more wave-instructions than all node steps together), so the refill trace kernel lets lanes with pending triangles
+// wait until enough of them have accumulated.  A lane's own sequence of operations is unchanged -- it only waits.
+template <bool STATS>
+PT_DEV bool ray_tri_phase(const DScene& S, RayState& r, Counters& cn)          // precondition: r.tg.y != 0
+{
+    uint32_t triangleIndex = 31u - (uint32_t)__clz((int)r.tg.y);
+    uint32_t triAddr = r.tg.x + triangleIndex * 3u;
+    intersect_triangle(S.tris, triAddr, r.o, r.d, r.hit);
+    if (STATS) cn.triTests++;
+    r.tg.y -= 1u << triangleIndex;
+    if (r.anyHit && r.hit.t < PT_FAR_PLANE) {
+        if (STATS && r.overflow) cn.overflows++;
+        return true;
+    }
+    return false;
+}
+
+template <bool STATS, class ST>
+PT_DEV bool ray_node_phase(const DScene& S, RayState& r, ST& st, Counters& cn)  // precondition: r.tg.y == 0
+{
+    if (r.ng.y <= 0x00FFFFFFu) {
+        if (r.sp > 0u) { --r.sp; r.ng = stack_pop(st, r.sp); }
+        else {
+            if (STATS && r.overflow) cn.overflows++;
+            return true;
+        }
+    }
+    if (r.ng.y > 0x00FFFFFFu) {
+        uint32_t mask = r.ng.y;
+        uint32_t childBitIndex = 31u - (uint32_t)__clz((int)mask);
+        uint32_t childNodeBaseIndex = r.ng.x;
+        r.ng.y &= ~(1u << childBitIndex);
+        if (r.ng.y > 0x00FFFFFFu) {
+            stack_push(st, r.sp, r.ng);
+            if (r.sp >= PT_BVH_STACK_SIZE) r.overflow = true;
+            r.sp++;
+            if (STATS) cn.maxStack = r.sp > cn.maxStack ? r.sp : cn.maxStack;
+        }
+        uint32_t slotIndex = (childBitIndex - 24u) ^ (r.octinv4 & 255u);
+        uint32_t relativeIndex = (uint32_t)__popc(mask & ~(0xFFFFFFFFu << slotIndex));
+        uint32_t childNodeIndex = childNodeBaseIndex + relativeIndex;
+        const uint4* np = S.nodes + (size_t)childNodeIndex * 5;
+        uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+        uint32_t hitmask = cwbvh_node_hitmask(r.o, r.invDir, r.octinv4, r.hit.t, n0, n1, n2, n3, n4);
+        if (STATS) cn.nodeVisits++;
+        r.ng.x = n1.x;
+        r.ng.y = (hitmask & 0xFF000000u) | (n0.w >> 24);
+        r.tg.x = n1.y;
+        r.tg.y = hitmask & 0x00FFFFFFu;
+    } else {
+        r.tg = r.ng;
+        r.ng = make_uint2(0u, 0u);
+    }
+    return false;
 }

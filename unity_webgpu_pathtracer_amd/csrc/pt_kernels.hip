@@ -16,7 +16,7 @@ namespace {
 #define PT_MK_MIN_WAVES 4      // waves per SIMD the register allocator must leave room for (4 = 128 VGPRs; measured best trade)
 #endif
 
-template <bool STATS>
+template <bool STATS, bool TLAS>
 __global__ __launch_bounds__(256, PT_MK_MIN_WAVES) void pt_megakernel(DScene S, PTFrameParams P, const float4* __restrict__ accumulated,
                                                      float4* __restrict__ output, PTTileMap tm,
                                                      unsigned long long* __restrict__ gstats)
@@ -48,8 +48,9 @@ __global__ __launch_bounds__(256, PT_MK_MIN_WAVES) void pt_megakernel(DScene S, 
 
     while (r.state != PS_DONE) {
         // ---- traversal pass (<= 3 rays per lane); ray slots rotate through registers: slot 0 is traced, slots 1, 2 move down
-        TraceHit ch;
-        ch.t = PT_FAR_PLANE; ch.u = 0.0f; ch.v = 0.0f; ch.triIndex = 0u;
+        HitRecord ch;
+        ch.h.t = PT_FAR_PLANE; ch.h.u = 0.0f; ch.h.v = 0.0f; ch.h.triIndex = 0u;
+        ch.pos = mk3(0.0f); ch.inst = 0u;
         bool occEnv = false, occLight = false;
         bool a0 = r.hasPending && r.env.valid != 0u, a1 = r.hasPending && r.light.valid != 0u, a2 = r.state == PS_TRACE;
         v3 o0 = r.neeOrigin, d0 = r.env.dir, o1 = r.neeOrigin, d1 = r.light.dir, o2 = r.ro, d2 = r.rd;
@@ -60,11 +61,14 @@ __global__ __launch_bounds__(256, PT_MK_MIN_WAVES) void pt_megakernel(DScene S, 
             a0 = a1; o0 = o1; d0 = d1;
             a1 = a2; o1 = o2; d1 = d2;
             if (active) {
-                TraceHit h;
-                h.t = PT_FAR_PLANE; h.u = 0.0f; h.v = 0.0f; h.triIndex = 0u;
-                traverse_cwbvh<STATS>(S, o, d, k < 2, h, st, cn);
-                if (k == 0) { occEnv = h.t < PT_FAR_PLANE; cn.shadowRays++; }
-                else if (k == 1) { occLight = h.t < PT_FAR_PLANE; cn.shadowRays++; }
+                HitRecord h;
+                h.h.t = PT_FAR_PLANE; h.h.u = 0.0f; h.h.v = 0.0f; h.h.triIndex = 0u;
+                h.pos = mk3(0.0f); h.inst = 0u;
+                bool occluded;
+                if (TLAS) occluded = traverse_tlas<STATS>(S, o, d, k < 2, h, st, cn);          // util/tlas.hlsl:334-352
+                else { traverse_cwbvh<STATS>(S, o, d, k < 2, h.h, st, cn); occluded = h.h.t < PT_FAR_PLANE; }
+                if (k == 0) { occEnv = occluded; cn.shadowRays++; }
+                else if (k == 1) { occLight = occluded; cn.shadowRays++; }
                 else { ch = h; cn.closestRays++; }
             }
         }
@@ -95,7 +99,12 @@ hipError_t pt_launch_megakernel(const DScene& S, const PTFrameParams& P, const f
 {
     dim3 grid((tm.blocksX + tm.world - 1) / tm.world, tm.blocksY, 1);
     dim3 block(256, 1, 1);
-    if (fullStats) hipLaunchKernelGGL(pt_megakernel<true>, grid, block, 0, stream, S, P, accumulated, output, tm, gstats);
-    else hipLaunchKernelGGL(pt_megakernel<false>, grid, block, 0, stream, S, P, accumulated, output, tm, gstats);
+    if (S.hasTlas) {
+        if (fullStats) hipLaunchKernelGGL((pt_megakernel<true, true>), grid, block, 0, stream, S, P, accumulated, output, tm, gstats);
+        else hipLaunchKernelGGL((pt_megakernel<false, true>), grid, block, 0, stream, S, P, accumulated, output, tm, gstats);
+    } else {
+        if (fullStats) hipLaunchKernelGGL((pt_megakernel<true, false>), grid, block, 0, stream, S, P, accumulated, output, tm, gstats);
+        else hipLaunchKernelGGL((pt_megakernel<false, false>), grid, block, 0, stream, S, P, accumulated, output, tm, gstats);
+    }
     return hipGetLastError();
 }

@@ -23,6 +23,7 @@ struct PTWfBuffers {
     float4 *neeO, *envD, *lightD;        // NEE shadow rays of the last shaded bounce
     float4 *envC, *lightC, *pthr;        // their contributions and the throughput they apply to
     float4* hit;                // [numSlots] (t, u, v, triIndex bits) written by trace kind 0
+    float4* hit2;               // [numSlots] HAS_TLAS only: (world hit position, instance index bits)
     uint8_t* occl;              // [2][numSlots] written by trace kinds 1, 2
     uint32_t* aliveFlags;       // [maxIterations]
     uint32_t* chunkHeads;       // [8 shards x 32 words]: work counters of the persistent trace kernel, one 128-B line each

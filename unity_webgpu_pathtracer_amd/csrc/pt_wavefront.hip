@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void pt_wf_init(PTFrameParams P, PTTileMap tm,
 #define PT_WF_LDS_STACK 8
 #endif
 
-template <bool STATS>
+template <bool STATS, bool TLAS>
 __global__ __launch_bounds__(256, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace(DScene S, PTWfBuffers B)
 {
     __shared__ uint2 s_stack[PT_LDS_STACK][256];
@@ -142,11 +142,17 @@ __global__ __launch_bounds__(256, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace(DScene
         TravStack st;
         st.lds = &s_stack[0][threadIdx.x];
         st.stride = 256u;
-        TraceHit h;
-        h.t = PT_FAR_PLANE; h.u = 0.0f; h.v = 0.0f; h.triIndex = 0u;
-        traverse_cwbvh<STATS>(S, o, d, kind != 0u, h, st, cn);
-        if (kind == 0u) { B.hit[slot] = make_float4(h.t, h.u, h.v, pt_asfloat(h.triIndex)); cn.closestRays++; }
-        else { B.occl[(size_t)(kind - 1u) * B.numSlots + slot] = h.t < PT_FAR_PLANE ? 1 : 0; cn.shadowRays++; }
+        HitRecord h;
+        h.h.t = PT_FAR_PLANE; h.h.u = 0.0f; h.h.v = 0.0f; h.h.triIndex = 0u;
+        h.pos = mk3(0.0f); h.inst = 0u;
+        bool occluded;
+        if (TLAS) occluded = traverse_tlas<STATS>(S, o, d, kind != 0u, h, st, cn);
+        else { traverse_cwbvh<STATS>(S, o, d, kind != 0u, h.h, st, cn); occluded = h.h.t < PT_FAR_PLANE; }
+        if (kind == 0u) {
+            B.hit[slot] = make_float4(h.h.t, h.h.u, h.h.v, pt_asfloat(h.h.triIndex));
+            if (TLAS) B.hit2[slot] = make_float4(h.pos.x, h.pos.y, h.pos.z, pt_asfloat(h.inst));
+            cn.closestRays++;
+        } else { B.occl[(size_t)(kind - 1u) * B.numSlots + slot] = occluded ? 1 : 0; cn.shadowRays++; }
     }
     flush_counters<STATS>(cn, B.statRows, (B.numSlots >> 6) + vb * 4u + (threadIdx.x >> 6), threadIdx.x & 63u);
 }
@@ -175,6 +181,9 @@ __global__ __launch_bounds__(256, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace(DScene
 #define PT_WF_STEP ray_microstep
 #else
 #define PT_WF_STEP ray_step
+#endif
+#ifndef PT_WF_TRI_THRESHOLD
+#define PT_WF_TRI_THRESHOLD 16u // run the triangle phase only when at least this many lanes have a triangle pending (0 = nested loop)
 #endif
 #ifndef PT_WF_TRACE_BLOCK
 #define PT_WF_TRACE_BLOCK 64u   // threads per workgroup of the refill trace kernel (one wave: a finished wave frees its slot at once)
@@ -251,13 +260,31 @@ __global__ __launch_bounds__(PT_WF_TRACE_BLOCK, PT_WF_TRACE_MIN_WAVES) void pt_w
         // ---- traverse until enough lanes have retired (or, once the range is exhausted, until all have)
         const uint32_t stopAt = cursor < nItems ? PT_WF_REFILL : 64u;
         do {
+#if PT_WF_TRI_THRESHOLD > 0
+            // phase scheduling: the node phase runs whenever a lane wants it; the (short, sparse) triangle phase only when
+            // enough lanes have a triangle pending, or when nobody can do anything else
+            const bool wantTri = have && rs.tg.y != 0u;
+            const uint32_t nT = (uint32_t)__popcll(__ballot(wantTri));
+            const uint32_t nN = (uint32_t)__popcll(__ballot(have && !wantTri));
+            bool fin = false;
+            if (nT >= PT_WF_TRI_THRESHOLD || nN == 0u) {
+                if (wantTri) fin = ray_tri_phase<STATS>(S, rs, cn);
+            }
+            if (have && !fin && rs.tg.y == 0u) fin = ray_node_phase<STATS>(S, rs, st, cn);
+            if (fin) {
+#else
             if (have) {
                 if (PT_WF_STEP<STATS>(S, rs, st, cn)) {
+#endif
                     if (myKind == 0u) B.hit[mySlot] = make_float4(rs.hit.t, rs.hit.u, rs.hit.v, pt_asfloat(rs.hit.triIndex));
                     else B.occl[(size_t)(myKind - 1u) * B.numSlots + mySlot] = rs.hit.t < PT_FAR_PLANE ? 1 : 0;
                     have = false;
+#if PT_WF_TRI_THRESHOLD > 0
+            }
+#else
                 }
             }
+#endif
             nIdle = (uint32_t)__popcll(__ballot(!have));
         } while (nIdle < stopAt);
     }
@@ -418,11 +445,13 @@ PT_DEV bool shade_slot(const DScene& S, const PTFrameParams& P, const PTTileMap&
         occEnv = B.occl[slot] != 0;
         occLight = B.occl[(size_t)B.numSlots + slot] != 0;
     }
-    TraceHit ch;
-    ch.t = PT_FAR_PLANE; ch.u = 0.0f; ch.v = 0.0f; ch.triIndex = 0u;
+    HitRecord ch;
+    ch.h.t = PT_FAR_PLANE; ch.h.u = 0.0f; ch.h.v = 0.0f; ch.h.triIndex = 0u;
+    ch.pos = mk3(0.0f); ch.inst = 0u;
     if (r.state == PS_TRACE) {
         float4 h = B.hit[slot];
-        ch.t = h.x; ch.u = h.y; ch.v = h.z; ch.triIndex = pt_asuint(h.w);
+        ch.h.t = h.x; ch.h.u = h.y; ch.h.v = h.z; ch.h.triIndex = pt_asuint(h.w);
+        if (S.hasTlas) { float4 h2 = B.hit2[slot]; ch.pos = xyz(h2); ch.inst = pt_asuint(h2.w); }
     }
     path_step<STATS, false>(S, P, r, ch, occEnv, occLight, px, py, py * P.OutputWidth + px, nullptr, nullptr, cn);
     store_path(B, slot, r, r.hasPending);
@@ -448,7 +477,7 @@ __global__ __launch_bounds__(256, PT_WF_SHADE_MIN_WAVES) void pt_wf_shade(DScene
 
 // cleanup: pixels still alive after the fixed number of iterations are run to completion here, one lane per slot with
 // the megakernel's loop (trace <= 3 rays, path_step, repeat).  Normally a handful of lanes; correctness for any path length.
-template <bool STATS>
+template <bool STATS, bool TLAS>
 __global__ __launch_bounds__(256, 2) void pt_wf_cleanup(DScene S, PTFrameParams P, PTTileMap tm, PTWfBuffers B)
 {
     __shared__ uint2 s_stack[PT_LDS_STACK][256];
@@ -470,21 +499,25 @@ __global__ __launch_bounds__(256, 2) void pt_wf_cleanup(DScene S, PTFrameParams 
             st.lds = &s_stack[0][threadIdx.x];
             st.stride = 256u;
             while (r.state != PS_DONE) {
-                TraceHit ch;
-                ch.t = PT_FAR_PLANE; ch.u = 0.0f; ch.v = 0.0f; ch.triIndex = 0u;
+                HitRecord ch;
+                ch.h.t = PT_FAR_PLANE; ch.h.u = 0.0f; ch.h.v = 0.0f; ch.h.triIndex = 0u;
+                ch.pos = mk3(0.0f); ch.inst = 0u;
                 bool occEnv = false, occLight = false;
                 if (r.hasPending && r.env.valid != 0u) {
-                    TraceHit h; h.t = PT_FAR_PLANE; h.u = 0.0f; h.v = 0.0f; h.triIndex = 0u;
-                    traverse_cwbvh<STATS>(S, r.neeOrigin, r.env.dir, true, h, st, cn);
-                    occEnv = h.t < PT_FAR_PLANE; cn.shadowRays++;
+                    HitRecord h = ch;
+                    if (TLAS) occEnv = traverse_tlas<STATS>(S, r.neeOrigin, r.env.dir, true, h, st, cn);
+                    else { traverse_cwbvh<STATS>(S, r.neeOrigin, r.env.dir, true, h.h, st, cn); occEnv = h.h.t < PT_FAR_PLANE; }
+                    cn.shadowRays++;
                 }
                 if (r.hasPending && r.light.valid != 0u) {
-                    TraceHit h; h.t = PT_FAR_PLANE; h.u = 0.0f; h.v = 0.0f; h.triIndex = 0u;
-                    traverse_cwbvh<STATS>(S, r.neeOrigin, r.light.dir, true, h, st, cn);
-                    occLight = h.t < PT_FAR_PLANE; cn.shadowRays++;
+                    HitRecord h = ch;
+                    if (TLAS) occLight = traverse_tlas<STATS>(S, r.neeOrigin, r.light.dir, true, h, st, cn);
+                    else { traverse_cwbvh<STATS>(S, r.neeOrigin, r.light.dir, true, h.h, st, cn); occLight = h.h.t < PT_FAR_PLANE; }
+                    cn.shadowRays++;
                 }
                 if (r.state == PS_TRACE) {
-                    traverse_cwbvh<STATS>(S, r.ro, r.rd, false, ch, st, cn);
+                    if (TLAS) traverse_tlas<STATS>(S, r.ro, r.rd, false, ch, st, cn);
+                    else traverse_cwbvh<STATS>(S, r.ro, r.rd, false, ch.h, st, cn);
                     cn.closestRays++;
                 }
                 path_step<STATS, false>(S, P, r, ch, occEnv, occLight, px, py, py * P.OutputWidth + px, nullptr, nullptr, cn);
@@ -567,6 +600,8 @@ hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const fl
     const uint32_t nb = B.numSlots >> 8;
     uint32_t launches = 0;
     hipError_t e;
+    const bool tlas = S.hasTlas != 0u;
+    if (tlas) traceVariant = 1;          // two-level traversal runs in the one-ray-per-lane trace kernel (not resumable yet)
     if ((e = hipMemsetAsync(B.aliveFlags, 0, sizeof(uint32_t) * B.maxIterations, stream)) != hipSuccess) return e;
     hipLaunchKernelGGL(pt_wf_init, dim3(nb), dim3(256), 0, stream, P, tm, B);
     launches++;
@@ -587,16 +622,24 @@ hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const fl
         } else if (traceVariant == 2) {
             if (fullStats) hipLaunchKernelGGL(pt_wf_trace_refill<true>, dim3(refillBlocks), dim3(PT_WF_TRACE_BLOCK), 0, stream, S, B);
             else hipLaunchKernelGGL(pt_wf_trace_refill<false>, dim3(refillBlocks), dim3(PT_WF_TRACE_BLOCK), 0, stream, S, B);
+        } else if (tlas) {
+            if (fullStats) hipLaunchKernelGGL((pt_wf_trace<true, true>), dim3(nb * 3u), dim3(256), 0, stream, S, B);
+            else hipLaunchKernelGGL((pt_wf_trace<false, true>), dim3(nb * 3u), dim3(256), 0, stream, S, B);
         } else {
-            if (fullStats) hipLaunchKernelGGL(pt_wf_trace<true>, dim3(nb * 3u), dim3(256), 0, stream, S, B);
-            else hipLaunchKernelGGL(pt_wf_trace<false>, dim3(nb * 3u), dim3(256), 0, stream, S, B);
+            if (fullStats) hipLaunchKernelGGL((pt_wf_trace<true, false>), dim3(nb * 3u), dim3(256), 0, stream, S, B);
+            else hipLaunchKernelGGL((pt_wf_trace<false, false>), dim3(nb * 3u), dim3(256), 0, stream, S, B);
         }
         if (fullStats) hipLaunchKernelGGL(pt_wf_shade<true>, dim3(nb), dim3(256), 0, stream, S, P, tm, B, it);
         else hipLaunchKernelGGL(pt_wf_shade<false>, dim3(nb), dim3(256), 0, stream, S, P, tm, B, it);
         launches += 2;
     }
-    if (fullStats) hipLaunchKernelGGL(pt_wf_cleanup<true>, dim3(nb), dim3(256), 0, stream, S, P, tm, B);
-    else hipLaunchKernelGGL(pt_wf_cleanup<false>, dim3(nb), dim3(256), 0, stream, S, P, tm, B);
+    if (tlas) {
+        if (fullStats) hipLaunchKernelGGL((pt_wf_cleanup<true, true>), dim3(nb), dim3(256), 0, stream, S, P, tm, B);
+        else hipLaunchKernelGGL((pt_wf_cleanup<false, true>), dim3(nb), dim3(256), 0, stream, S, P, tm, B);
+    } else {
+        if (fullStats) hipLaunchKernelGGL((pt_wf_cleanup<true, false>), dim3(nb), dim3(256), 0, stream, S, P, tm, B);
+        else hipLaunchKernelGGL((pt_wf_cleanup<false, false>), dim3(nb), dim3(256), 0, stream, S, P, tm, B);
+    }
     if (orderAfter && (e = hipStreamWaitEvent(stream, orderAfter, 0)) != hipSuccess) return e;
     if (zeroOutputFirst &&
         (e = hipMemsetAsync(output, 0, (size_t)P.OutputWidth * P.OutputHeight * sizeof(float4), stream)) != hipSuccess) return e;

@@ -22,12 +22,55 @@ class BVHScene:
 
     def __init__(self, scene: Scene):
         self.scene = scene
-        # BVHScene.cs:629-659: BuildBVH over the world-space triangle soup, copy node/triangle bytes out
-        self.bvh_nodes, self.bvh_tris = plugin.build_cwbvh(scene.vertices)
+        self.tlas_data = None
+        self.tlas_index_offset = 0
+        self.gpu_instances = None
+        if scene.use_tlas:
+            self._build_two_level(scene)
+        else:
+            # BVHScene.cs:629-659: BuildBVH over the world-space triangle soup, copy node/triangle bytes out
+            self.bvh_nodes, self.bvh_tris = plugin.build_cwbvh(scene.vertices)
         self.tri_attrs = np.ascontiguousarray(scene.tri_attrs)
         self.materials = np.ascontiguousarray(scene.materials, dtype=np.float32)
         self.lights = np.ascontiguousarray(scene.lights, dtype=np.float32)
         self.texture_data = np.ascontiguousarray(scene.texture_data, dtype=np.uint32)
+
+    def _build_two_level(self, scene: Scene):
+        """BVHScene.cs:600-758 with _useTLAS: one BLAS per unique mesh (local space), node / triangle buffers back to
+        back, one GPUInstance + BLASInstance per renderer, BuildTLAS over the renderers' world bounds, TLASData =
+        TLAS nodes followed by the instance indices at TLASIndexOffset."""
+        from .scenes import instance_world_bounds
+        nodes, tris, node_off, tri_off = [], [], [], []
+        n_off = t_off = 0
+        for t0, n in scene.mesh_ranges:
+            nb, tb = plugin.build_cwbvh(scene.vertices[t0 * 3:(t0 + n) * 3])
+            nodes.append(nb)
+            tris.append(tb)
+            node_off.append(n_off)
+            tri_off.append(t_off)
+            n_off += nb.nbytes
+            t_off += tb.nbytes
+        self.bvh_nodes = np.concatenate(nodes)
+        self.bvh_tris = np.concatenate(tris)
+        gi = np.zeros(len(scene.instances), dtype=abi.GPU_INSTANCE)
+        bi = np.zeros(len(scene.instances), dtype=abi.BLAS_INSTANCE)
+        for k, (mesh, l2w, material) in enumerate(scene.instances):
+            w2l = np.linalg.inv(l2w)
+            gi[k]["localToWorld"] = l2w.T.reshape(16).astype(np.float32)       # Matrix4x4 memory order: (r, c) at c*4 + r
+            gi[k]["worldToLocal"] = w2l.T.reshape(16).astype(np.float32)
+            gi[k]["bvhOffset"] = node_off[mesh] // 80                            # kBVHNodeSize
+            gi[k]["triOffset"] = tri_off[mesh] // 16                             # kBVHTriSize: float4 units
+            gi[k]["triAttributeOffset"] = scene.mesh_ranges[mesh][0]             # in triangles
+            gi[k]["materialIndex"] = material
+            t0, n = scene.mesh_ranges[mesh]
+            lo, hi = instance_world_bounds(scene.vertices[t0 * 3:(t0 + n) * 3], l2w)
+            bi[k]["localToWorld"], bi[k]["worldToLocal"] = gi[k]["localToWorld"], gi[k]["worldToLocal"]
+            bi[k]["aabbMin"], bi[k]["aabbMax"], bi[k]["blasIndex"] = lo, hi, k
+        tlas_nodes, tlas_idx = plugin.build_tlas(bi)
+        self.tlas_index_offset = tlas_nodes.nbytes // 4
+        self.tlas_data = np.concatenate([tlas_nodes.view(np.float32), tlas_idx.view(np.float32)])
+        self.gpu_instances = gi
+        self.blas_instances = bi
 
     def desc(self) -> abi.PTSceneDesc:
         d = abi.PTSceneDesc()
@@ -44,6 +87,12 @@ class BVHScene:
         d.textureData = self.texture_data.ctypes.data if self.texture_data.size else None
         d.textureDataUints = self.texture_data.size
         d.features = self.scene.features
+        if self.tlas_data is not None:
+            d.tlasData = self.tlas_data.ctypes.data
+            d.tlasDataFloats = self.tlas_data.size
+            d.tlasIndexOffset = self.tlas_index_offset
+            d.instanceCount = self.gpu_instances.shape[0]
+            d.gpuInstances = self.gpu_instances.ctypes.data
         return d
 
     def PrepareShader(self, ctx):

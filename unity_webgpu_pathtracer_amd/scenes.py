@@ -55,6 +55,14 @@ class Scene:
     environment_color: tuple = (0.0, 0.0, 0.0, 1.0)
     environment_intensity: float = 1.0
     extras: dict = field(default_factory=dict)
+    # HAS_TLAS scenes (BVHScene.cs:600-758): `vertices` / `tri_attrs` hold the unique meshes back to back in LOCAL space,
+    # mesh_ranges[i] = (first triangle, triangle count) of mesh i, instances[j] = (mesh index, localToWorld 4x4, material index)
+    mesh_ranges: list = None
+    instances: list = None
+
+    @property
+    def use_tlas(self):
+        return self.instances is not None
 
     @property
     def tri_count(self):
@@ -67,6 +75,8 @@ class Scene:
             f |= abi.PT_FEATURE_HAS_LIGHTS
         if self.texture_data.size > 0:
             f |= abi.PT_FEATURE_HAS_TEXTURES
+        if self.use_tlas:
+            f |= abi.PT_FEATURE_HAS_TLAS
         return f
 
 
@@ -722,12 +732,114 @@ def furnace(albedo: float = 0.8) -> Scene:
                  environment_mode=0, environment_color=(1.0, 1.0, 1.0, 1.0), environment_intensity=1.0)
 
 
+# ---------------------------------------------------------------------------------------
+# instanced scene for the HAS_TLAS variant (util/tlas.hlsl)
+# ---------------------------------------------------------------------------------------
+def _trs(translate=(0, 0, 0), rotate_y_deg=0.0, rotate_x_deg=0.0, scale=(1, 1, 1)):
+    ry, rx = np.radians(rotate_y_deg), np.radians(rotate_x_deg)
+    Ry = np.array([[np.cos(ry), 0, np.sin(ry), 0], [0, 1, 0, 0], [-np.sin(ry), 0, np.cos(ry), 0], [0, 0, 0, 1]])
+    Rx = np.array([[1, 0, 0, 0], [0, np.cos(rx), -np.sin(rx), 0], [0, np.sin(rx), np.cos(rx), 0], [0, 0, 0, 1]])
+    S = np.diag([scale[0], scale[1], scale[2], 1.0])
+    T = np.eye(4)
+    T[:3, 3] = translate
+    return T @ Ry @ Rx @ S
+
+
+def instanced_scene(count: int = 14, detail: int = 12) -> Scene:
+    """A floor plus `count` instances of three small meshes (sphere, box, cone) with rotations, translations and
+    non-uniform scales -- the last on purpose: the reference compares instance-LOCAL hit parameters against the
+    world-space distance of the best hit so far (util/tlas.hlsl:47,216-217), and the restatement must keep that."""
+    rng = np.random.RandomState(17)
+    meshes = []
+    sb = SoupBuilder()
+    sb.uv_sphere((0, 0, 0), 0.5, detail * 2, detail, 0)
+    meshes.append(sb.finish())
+    sb = SoupBuilder()
+    for o, eu, ev, n in (((-.5, -.5, -.5), (1, 0, 0), (0, 1, 0), (0, 0, -1)), ((-.5, -.5, .5), (1, 0, 0), (0, 1, 0), (0, 0, 1)),
+                         ((-.5, -.5, -.5), (0, 0, 1), (0, 1, 0), (-1, 0, 0)), ((.5, -.5, -.5), (0, 0, 1), (0, 1, 0), (1, 0, 0)),
+                         ((-.5, -.5, -.5), (1, 0, 0), (0, 0, 1), (0, -1, 0)), ((-.5, .5, -.5), (1, 0, 0), (0, 0, 1), (0, 1, 0))):
+        sb.quad(o, eu, ev, n, 2, 2, 0)
+    meshes.append(sb.finish())
+    sb = SoupBuilder()
+
+    def cone(U, V):
+        ang = U * 2 * np.pi
+        r = 0.5 * (1.0 - V)
+        pos = np.stack([r * np.cos(ang), V - 0.5, r * np.sin(ang)], axis=-1)
+        nrm = np.stack([np.cos(ang), np.full_like(ang, 0.5), np.sin(ang)], axis=-1)
+        tan = np.stack([-np.sin(ang), np.zeros_like(ang), np.cos(ang)], axis=-1)
+        return pos, nrm, tan, np.stack([U, V], axis=-1)
+    sb.grid(cone, detail * 2, detail // 2, 0)
+    meshes.append(sb.finish())
+    sb = SoupBuilder()
+    sb.quad((-6, 0, -6), (12, 0, 0), (0, 0, 12), (0, 1, 0), 6, 6, 0, uv_scale=(6, 6))
+    meshes.append(sb.finish())
+
+    verts = np.concatenate([m[0] for m in meshes])
+    attrs = np.concatenate([m[1] for m in meshes])
+    ranges, start = [], 0
+    for m in meshes:
+        n = m[0].shape[0] // 3
+        ranges.append((start, n))
+        start += n
+    mats = np.stack([
+        pack_material(color=(0.8, 0.8, 0.8, 1), roughness=0.9),                                   # 0 floor
+        pack_material(color=(0.8, 0.2, 0.2, 1), roughness=0.4),
+        pack_material(color=(0.8, 0.75, 0.3, 1), roughness=0.25, metallic=1.0),
+        pack_material(color=(0.2, 0.4, 0.8, 1), roughness=0.6, clearcoat=1.0, clearcoat_gloss=0.8),
+        pack_material(color=(0.9, 0.95, 1.0, 0.2), roughness=0.05, ior=1.45),
+    ])
+    instances = [(3, _trs(), 0)]
+    for k in range(count):
+        mesh = k % 3
+        pos = (rng.uniform(-3.5, 3.5), rng.uniform(0.5, 1.6), rng.uniform(-3.0, 3.5))
+        sc = (rng.uniform(0.6, 1.5), rng.uniform(0.6, 1.5), rng.uniform(0.6, 1.5)) if k % 2 else (1.0, 1.0, 1.0)
+        instances.append((mesh, _trs(pos, rng.uniform(0, 360), rng.uniform(-30, 30), sc), 1 + k % 4))
+    lights = np.stack([pack_rect_light(center=(0.0, 5.0, 0.0), right=(1, 0, 0), up=(0, 0, 1), size=(2.0, 2.0),
+                                       color=(14, 13, 12), rng=40.0)])
+    return Scene("instanced", verts, attrs, mats, lights, np.zeros(0, dtype=np.uint32),
+                 Camera(eye=(0.0, 3.0, -7.5), target=(0.0, 0.8, 0.0), vfov_deg=45.0),
+                 environment_mode=0, environment_color=(0.45, 0.55, 0.75, 1.0), environment_intensity=0.8,
+                 mesh_ranges=ranges, instances=instances)
+
+
+def instance_world_bounds(local_verts, local_to_world):
+    """renderer.bounds (BVHScene.cs:690): world AABB of the transformed local AABB's eight corners."""
+    lo, hi = local_verts[:, :3].min(axis=0).astype(np.float64), local_verts[:, :3].max(axis=0).astype(np.float64)
+    corners = np.array([[x, y, z, 1.0] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])])
+    w = (local_to_world @ corners.T).T[:, :3]
+    return w.min(axis=0).astype(F32), w.max(axis=0).astype(F32)
+
+
+def bake_instances(scene: Scene) -> Scene:
+    """The same geometry as a flat world-space triangle soup (what the non-TLAS path of BVHScene.cs would upload)."""
+    P, A = [], []
+    for mesh, l2w, material in scene.instances:
+        t0, n = scene.mesh_ranges[mesh]
+        v = scene.vertices[t0 * 3:(t0 + n) * 3].astype(np.float64)
+        h = np.concatenate([v[:, :3], np.ones((v.shape[0], 1))], axis=1)
+        w = (l2w @ h.T).T
+        out = np.zeros((v.shape[0], 4), F32)
+        out[:, :3] = w[:, :3]
+        P.append(out)
+        a = scene.tri_attrs[t0:t0 + n].copy()
+        nt = np.linalg.inv(l2w)[:3, :3].T
+        for k in range(3):
+            nn = (nt @ a[f"normal{k}"].astype(np.float64).T).T
+            a[f"normal{k}"] = (nn / np.linalg.norm(nn, axis=1, keepdims=True)).astype(F32)
+        a["materialIndex"] = material
+        A.append(a)
+    return Scene(scene.name + "_baked", np.concatenate(P), np.concatenate(A), scene.materials, scene.lights, scene.texture_data,
+                 scene.camera, scene.environment_mode, scene.environment_color, scene.environment_intensity)
+
+
 SCENES = {
     "cornell": cornell_box,
     "bunny": bunny_box,
     "sponza": sponza_atrium,
     "zoo": material_zoo,
     "furnace": furnace,
+    "instanced": instanced_scene,
 }
 
 
