@@ -106,7 +106,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=8)
     ap.add_argument("--bounces", type=int, default=4)
-    ap.add_argument("--schedule", type=int, default=1, help="0 megakernel, 1 wavefront (default), 2/3 wavefront variants")
+    ap.add_argument("--schedule", type=int, default=-1, help="-1 auto (default: wavefront, megakernel for <=16-node scenes), 0 megakernel, 1 wavefront, 2/3 variants")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alg-replay", action="store_true", help="profiling runs: skip the untimed full-counter replay (roofline.achieved is then null)")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads reported under 'other_workloads'")
@@ -209,6 +209,7 @@ def main():
             res["max_stack_depth"] = int(fs.maxStackDepth)
         if distributed and full:
             dist.barrier()
+        res["schedule"] = pt.schedule()
         res["_pt"], res["_scene"] = pt, scene
         return res
 
@@ -236,12 +237,12 @@ def main():
             "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload]['desc']}, {W}x{H}, {SPP} spp/pass, depth {args.bounces}, "
                                    f"progressive passes (CurrentSample = 8k)",
                        "tris": main_res["tris"], "rays_per_step": round(main_res["rays_per_step"]),
-                       "msamples_per_s": round(main_res["msamples_per_s"], 3), "schedule": args.schedule,
+                       "msamples_per_s": round(main_res["msamples_per_s"], 3), "schedule": main_res["schedule"],
                        "sharding": "interleaved 16x16 blocks, one RCCL reduce per frame" if distributed else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                          "kernel": {0: "pt_megakernel", 1: "pt_wf_trace_refill + pt_wf_shade (whole pass)", 2: "pt_wf_trace + pt_wf_shade (whole pass)",
-                                    3: "pt_wf_trace_persist + pt_wf_shade (whole pass)"}[args.schedule],
+                                    3: "pt_wf_trace_persist + pt_wf_shade (whole pass)"}[main_res["schedule"]],
                          "kernel_ms": round(main_res["kernel_ms"], 4), "pass_span_ms": round(main_res["pass_span_ms"], 4),
                          "algorithmic_bytes_per_launch": round(main_res["alg_bytes_per_launch"]),
                          "counters_per_launch": {k: round(v) for k, v in main_res["counters_per_launch"].items()},
@@ -255,7 +256,8 @@ def main():
                 continue
             r = run_workload(name, max(2, args.steps // 2), 1, full=False)
             r["_pt"].close()
-            extra[name] = {"mrays_per_s": round(r["mrays_per_s"], 3), "ms_per_step": round(r["ms_per_step"], 4), "tris": r["tris"]}
+            extra[name] = {"mrays_per_s": round(r["mrays_per_s"], 3), "ms_per_step": round(r["ms_per_step"], 4), "tris": r["tris"],
+                           "schedule": r["schedule"]}
         if out is not None:
             out["other_workloads"] = extra
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

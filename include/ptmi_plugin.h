@@ -206,11 +206,14 @@ PT_API int PTGetTimings(PTContext* ctx, PTTimings* out);
 PT_API int PTResetTimings(PTContext* ctx);
 
 /* Select the kernel schedule.  All schedules produce bit-identical frames and counters:
+ *  -1  auto (default): 1, except for scenes whose BVH has <= 16 nodes (no traversal to speak of), which use 0
  *   0  megakernel: one lane per pixel, one launch per pass
- *   1  wavefront (default): slot-indexed path state, refill trace kernel + shade kernel, host-sync-free, passes overlap
+ *   1  wavefront: slot-indexed path state, refill trace kernel + shade kernel, host-sync-free, passes overlap
  *   2  wavefront with the plain one-ray-per-lane trace kernel
  *   3  wavefront with the persistent dynamic-chunk trace kernel */
 PT_API int PTSetSchedule(PTContext* ctx, int schedule);
+/* The schedule (0..3) the next pass will run with the current scene: resolves -1 (auto).  Negative = error code. */
+PT_API int PTGetSchedule(PTContext* ctx);
 /* Wavefront schedules: number of trace+shade iterations launched per pass before the cleanup kernel finishes whatever is
  * still alive.  0 (default) = SamplesPerPass * (MaxRayBounces + 2) + 4.  Any value gives the same frame; it only moves
  * work between the wavefront kernels and the cleanup kernel (tuning / test knob). */

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void pt_wf_init(PTFrameParams P, PTTileMap tm,
 #endif
 
 template <bool STATS, bool TLAS>
-__global__ __launch_bounds__(256, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace(DScene S, PTWfBuffers B)
+__global__ __launch_bounds__(256, 4) void pt_wf_trace(DScene S, PTWfBuffers B)
 {
     __shared__ uint2 s_stack[PT_LDS_STACK][256];
     const uint32_t nb = B.numSlots >> 8;

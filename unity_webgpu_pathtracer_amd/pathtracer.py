@@ -217,6 +217,13 @@ class PathTracer:
     def set_schedule(self, schedule: int):
         plugin.check(self.lib.PTSetSchedule(self.ctx, schedule))
 
+    def schedule(self) -> int:
+        """The schedule the next pass runs with (auto resolved against the current scene)."""
+        rc = self.lib.PTGetSchedule(self.ctx)
+        if rc < 0:
+            plugin.check(rc)
+        return rc
+
     def set_wavefront_iterations(self, n: int):
         plugin.check(self.lib.PTSetWavefrontIterations(self.ctx, n))
 
