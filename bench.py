@@ -25,6 +25,7 @@ import json
 import os
 import sys
 import time
+import zlib
 
 import numpy as np
 
@@ -107,6 +108,8 @@ def main():
     ap.add_argument("--spp", type=int, default=8)
     ap.add_argument("--bounces", type=int, default=4)
     ap.add_argument("--schedule", type=int, default=-1, help="-1 auto (default: wavefront, megakernel for <=16-node scenes), 0 megakernel, 1 wavefront, 2/3 variants")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL (default); gloo only to rehearse N>1 on a one-GPU box")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alg-replay", action="store_true", help="profiling runs: skip the untimed full-counter replay (roofline.achieved is then null)")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads reported under 'other_workloads'")
@@ -122,10 +125,15 @@ def main():
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if distributed:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     W, H, SPP = args.width, args.height, args.spp
 
@@ -136,6 +144,9 @@ def main():
                         rank=rank, world_size=world)
         pt.set_schedule(args.schedule)
         frames = [torch.zeros((H, W, 4), dtype=torch.float32, device=device) for _ in range(2)]
+        # N > 1: the rank's two frames keep its own tiles (they are the next pass's AccumulatedOutput); the frame is
+        # assembled on rank 0 in a third buffer, so nothing depends on what a reduce leaves in non-root buffers
+        assembled = torch.zeros((H, W, 4), dtype=torch.float32, device=device) if distributed else None
         ext = torch.cuda.ExternalStream(pt.stream(), device=device)
         torch.cuda.synchronize(device)
 
@@ -144,7 +155,8 @@ def main():
             pt.render_pass_to(p, frames[cur].data_ptr(), frames[1 - cur].data_ptr() if k > 0 else 0)
             if distributed:
                 with torch.cuda.stream(ext):
-                    dist.reduce(frames[cur], dst=0, op=dist.ReduceOp.SUM)      # RCCL over xGMI, once per frame
+                    assembled.copy_(frames[cur], non_blocking=True)
+                    dist.reduce(assembled, dst=0, op=dist.ReduceOp.SUM)       # RCCL over xGMI, once per frame
 
         def sync_all():
             pt.synchronize()
@@ -175,6 +187,8 @@ def main():
         st = pt.stats()
         tm = pt.timings()
         pt.set_profiling(False)
+        final = assembled if distributed else frames[1 - cur]
+        crc = zlib.crc32(final.cpu().numpy().tobytes()) if (full and rank == 0) else 0   # identical for every N: owned tiles sum with zeros
         rays = torch.tensor([st.rays, st.closestHitRays, st.shadowRays, st.paths], dtype=torch.float64, device=device)
         el = torch.tensor([elapsed], dtype=torch.float64, device=device)
         if distributed:
@@ -190,7 +204,7 @@ def main():
             "msamples_per_s": float(rays[3].item()) / elapsed / 1e6,
             "kernel_ms": region_ms / steps,                        # device time per pass over the timed region (passes may overlap)
             "pass_span_ms": tm.kernelMsTotal / max(1, tm.passes),  # first-launch-to-resolve span of one pass
-            "tris": scene.tri_count,
+            "tris": scene.tri_count, "frame_crc32": crc,
         }
         if full and rank == 0 and not args.no_alg_replay:
             # algorithmic bytes: replay the same timed steps once, untimed, with the full-counter kernel variant
@@ -238,6 +252,7 @@ def main():
                                    f"progressive passes (CurrentSample = 8k)",
                        "tris": main_res["tris"], "rays_per_step": round(main_res["rays_per_step"]),
                        "msamples_per_s": round(main_res["msamples_per_s"], 3), "schedule": main_res["schedule"],
+                       "frame_crc32": main_res["frame_crc32"],
                        "sharding": "interleaved 16x16 blocks, one RCCL reduce per frame" if distributed else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
