@@ -35,6 +35,13 @@ def load_library():
         return _lib
     if not os.path.exists(LIB_PATH):
         build_library()
+    # PyTorch-ROCm ships its own libamdhip64 under the same SONAME as /opt/rocm's.  Whichever loads first serves the whole
+    # process; torch only finds its GPUs through its own copy, so a host that hands torch buffers to PTRenderPassTo must
+    # let torch load first.  (The plugin itself is happy with either copy; a host without torch is unaffected.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, i32, u32p = C.c_void_p, C.c_int, C.POINTER(C.c_uint32)
     sig = {
