@@ -235,6 +235,32 @@ PT_HD float pt_acos(float x)
     return 1.5707963267948966192f - pt_asin_kernel(x, x * x);
 }
 
+/* ---- atan / atan2 / fmod  (environment map, util/sky.hlsl:45-53) ----------------------- */
+PT_HD float pt_atan(float x)
+{
+    /* range reduction at tan(pi/8) and tan(3pi/8), degree-4 odd polynomial on the reduced argument (|error| < 2 ulp) */
+    float a = pt_abs(x), y = 0.0f;
+    if (a > 2.414213562373095f) { y = 1.5707963267948966192f; a = -(1.0f / a); }
+    else if (a > 0.4142135623730950f) { y = 0.7853981633974483096f; a = (a - 1.0f) / (a + 1.0f); }
+    float z = a * a;
+    y = y + ((((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * a + a);
+    return x < 0.0f ? -y : y;
+}
+PT_HD float pt_atan2(float y, float x)
+{
+    /* HLSL atan2(y, x): quadrant-correct angle in [-pi, pi]; (0, 0) -> 0 */
+    if (pt_isnan(x) || pt_isnan(y)) return pt_asfloat(0x7FC00000u);
+    if (x == 0.0f) {
+        if (y == 0.0f) return 0.0f;
+        return y > 0.0f ? 1.5707963267948966192f : -1.5707963267948966192f;
+    }
+    float r = pt_atan(y / x);
+    if (x < 0.0f) r = (y < 0.0f) ? r - 3.14159265358979323846f : r + 3.14159265358979323846f;
+    return r;
+}
+PT_HD float pt_trunc(float x) { return __builtin_truncf(x); }
+PT_HD float pt_fmod(float x, float y) { return x - y * pt_trunc(x / y); }     /* HLSL fmod: sign of x */
+
 /* ---- the reference's hash RNG.  util/random.hlsl:5-16 (uint32 exact) ------------------ */
 PT_HD void pt_rng_next(uint32_t* state)
 {

@@ -74,6 +74,7 @@ typedef struct PTContext PTContext;   /* opaque; one per GPU (one process per GP
 #define PT_FEATURE_HAS_LIGHTS    0x1u   /* HAS_LIGHTS   (PathTracer.cs:372,469) */
 #define PT_FEATURE_HAS_TEXTURES  0x2u   /* HAS_TEXTURES (PathTracer.cs:185)     */
 #define PT_FEATURE_HAS_TLAS      0x4u   /* HAS_TLAS     (BVHScene.cs:145-149): two-level traversal, util/tlas.hlsl       */
+#define PT_FEATURE_HAS_ENVIRONMENT_TEXTURE 0x8u   /* HAS_ENVIRONMENT_TEXTURE (PathTracer.cs:119-143): util/sky.hlsl:7-88 */
 
 /* The buffers BVHScene.PrepareShader binds (BVHScene.cs:151-166) + Lights (PathTracer.cs:471).
  * All pointers are HOST pointers; PTSetScene copies them into HBM. */
@@ -90,6 +91,13 @@ typedef struct PTSceneDesc {
     const float*    tlasData;        uint64_t tlasDataFloats;    /* "TLASData": PTTlasNode[] (16 floats each) then the instance indices */
     uint32_t        tlasIndexOffset; uint32_t instanceCount;     /* "TLASIndexOffset" (in floats); number of PTGpuInstance           */
     const void*     gpuInstances;                                /* PTGpuInstance[]        "BLASInstances"                            */
+    /* HAS_ENVIRONMENT_TEXTURE only: the RGBAFloat copy of PathTracer.environmentTexture (PathTracer.cs:125-137), envWidth x
+     * envHeight float4, in the order of the readback array `data[i]` the reference builds its CDF from (PathTracer.cs:297-306).
+     * PTSetScene builds "EnvironmentCDF" / EnvironmentCdfSum from it exactly as OnEnvTexReadback does (sequential fp32 sum of
+     * Color.grayscale).  SampleLevel(uv) is restated as bilinear with clamp addressing; memory row r is the texel row at
+     * v = 1 - (r + 0.5) / envHeight, which makes SampleEnvMap's `uv.y = 1 - uv.y` (sky.hlsl:71) address the row whose CDF entry
+     * it picked.  (Sampler state and row order belong to Unity's platform layer: parity unpinned there, see DESIGN.md.) */
+    const float*    envTexture;      uint32_t envWidth;  uint32_t envHeight;
 } PTSceneDesc;
 
 /* The uniform block PathTracer.OnRenderImage sets every frame (PathTracer.cs:230-249;

@@ -112,6 +112,10 @@ struct SceneView {
     const float* tlas; uint64_t tlasFloats; uint32_t tlasIndexOffset;
     const PTGpuInstance* instances; uint32_t instanceCount;
     bool hasLights, hasTextures, hasTlas;
+    // HAS_ENVIRONMENT_TEXTURE: "EnvironmentTexture" texels (RGBAFloat), "EnvironmentCDF", EnvironmentCdfSum, width, height
+    const PTFloat4* envTexture; std::vector<float> EnvironmentCDF; float EnvironmentCdfSum;
+    int32_t EnvironmentTextureWidth, EnvironmentTextureHeight;
+    bool hasEnvironmentTexture;
 };
 
 struct Ctx {
@@ -981,7 +985,88 @@ inline f3 RandomCosineHemisphere(f3 normal, uint32_t& rng)
     return pt_sin(theta) * (pt_cos(phi) * onb.r0 + pt_sin(phi) * onb.r1 + pt_cos(theta) * onb.r2);
 }
 
-inline f4 SampleSkyRadiance(const Ctx& c, f3 direction, uint32_t rayDepth)
+// Texture2D.SampleLevel(sampler, uv, 0) for the environment copy (an ARGBFloat RenderTexture: bilinear filter, clamp
+// wrap).  Restated in fp32: texel centres at (i + 0.5)/size, weights = fractional parts, a + t (b - a) blends, x first.
+// Array row r (the order of the readback `data[i]`) sits at v = 1 - (r + 0.5)/H.  The hardware's fixed-point filter
+// weights and Unity's per-platform row order are not restated: parity unpinned here (oracle/pt_oracle.h).
+inline f3 EnvSampleLevel(const SceneView& S, f2 uv)
+{
+    const int32_t W = S.EnvironmentTextureWidth, H = S.EnvironmentTextureHeight;
+    float tx = uv.x * (float)W - 0.5f;
+    float ty = (1.0f - uv.y) * (float)H - 0.5f;
+    float bx = pt_floor(tx), by = pt_floor(ty);
+    float wx = tx - bx, wy = ty - by;
+    auto clampi = [](int32_t v, int32_t hi) { return v < 0 ? 0 : (v > hi ? hi : v); };
+    int32_t ix = pt_f2i(bx), iy = pt_f2i(by);
+    int32_t ix1 = ix < 2147483647 ? ix + 1 : ix, iy1 = iy < 2147483647 ? iy + 1 : iy;
+    ix = clampi(ix, W - 1); ix1 = clampi(ix1, W - 1); iy = clampi(iy, H - 1); iy1 = clampi(iy1, H - 1);
+    auto texel = [&](int32_t x, int32_t y) { const PTFloat4& t = S.envTexture[(size_t)y * W + x]; return V3(t.x, t.y, t.z); };
+    f3 t00 = texel(ix, iy), t10 = texel(ix1, iy), t01 = texel(ix, iy1), t11 = texel(ix1, iy1);
+    f3 rowA = V3(pt_lerp(t00.x, t10.x, wx), pt_lerp(t00.y, t10.y, wx), pt_lerp(t00.z, t10.z, wx));
+    f3 rowB = V3(pt_lerp(t01.x, t11.x, wx), pt_lerp(t01.y, t11.y, wx), pt_lerp(t01.z, t11.z, wx));
+    return V3(pt_lerp(rowA.x, rowB.x, wy), pt_lerp(rowA.y, rowB.y, wy), pt_lerp(rowA.z, rowB.z, wy));
+}
+
+inline f2 BinarySearch(const SceneView& S, float value)                              // util/sky.hlsl:7-42
+{
+    const int32_t W = S.EnvironmentTextureWidth, H = S.EnvironmentTextureHeight;
+    const float* EnvironmentCDF = S.EnvironmentCDF.data();
+    int lower = 0;
+    int upper = H - 1;
+    while (lower < upper) {
+        int mid = (lower + upper) >> 1;
+        int idx = mid * W + W - 1;
+        if (value < EnvironmentCDF[idx]) upper = mid;
+        else lower = mid + 1;
+    }
+    int y = lower < 0 ? 0 : (lower > H - 1 ? H - 1 : lower);
+    lower = 0;
+    upper = W - 1;
+    while (lower < upper) {
+        int mid = (lower + upper) >> 1;
+        int idx = y * W + mid;
+        if (value < EnvironmentCDF[idx]) upper = mid;
+        else lower = mid + 1;
+    }
+    int x = lower < 0 ? 0 : (lower > W - 1 ? W - 1 : lower);
+    return {(float)x / (float)W, (float)y / (float)H};
+}
+
+inline f4 EvalEnvMap(const Ctx& c, f3 r, float intensity)                             // util/sky.hlsl:44-64
+{
+    const SceneView& S = *c.S;
+    float theta = pt_acos(pt_clamp(r.y, -1.0f, 1.0f));
+    float r_atan = pt_atan2(r.z, r.x);
+    f2 uv = f2{(PT_PI + r_atan) * PT_INV_TWO_PI, 1.0f - theta * PT_INV_PI} + f2{c.P->EnvironmentMapRotation, 0.0f};
+    uv.x = pt_fmod(uv.x, 1.0f);
+    uv.y = pt_fmod(uv.y, 1.0f);
+    if (uv.x < 0.0f) uv.x += 1.0f;
+    if (uv.y < 0.0f) uv.y += 1.0f;
+    f3 color = EnvSampleLevel(S, uv);
+    float pdf = Luminance(color) / S.EnvironmentCdfSum;
+    pdf = (pdf * (float)S.EnvironmentTextureWidth * (float)S.EnvironmentTextureHeight) / (PT_TWO_PI * PT_PI * pt_sin(theta));
+    f3 ci = color * intensity;
+    return {ci.x, ci.y, ci.z, pdf};
+}
+
+inline f4 SampleEnvMap(const Ctx& c, f3& color, uint32_t& rngState)                   // util/sky.hlsl:66-88
+{
+    const SceneView& S = *c.S;
+    float rnd = RandomFloat(rngState) * S.EnvironmentCdfSum;
+    f2 uv = BinarySearch(S, rnd);
+    uv.y = 1.0f - uv.y;
+    color = EnvSampleLevel(S, uv);
+    float pdf = Luminance(color) / S.EnvironmentCdfSum;
+    uv.x -= c.P->EnvironmentMapRotation;
+    float phi = uv.x * PT_TWO_PI;
+    float theta = uv.y * PT_PI;
+    float sinTheta = pt_sin(theta);
+    if (sinTheta == 0.0f) pdf = 0.0f;
+    return {-sinTheta * pt_cos(phi), pt_cos(theta), -sinTheta * pt_sin(phi),
+            (pdf * (float)S.EnvironmentTextureWidth * (float)S.EnvironmentTextureHeight) / (PT_TWO_PI * PT_PI * sinTheta)};
+}
+
+inline f4 SampleSkyRadiance(const Ctx& c, f3 direction, uint32_t rayDepth)            // util/sky.hlsl:90-129
 {
     const PTFrameParams& P = *c.P;
     f4 radiance = {0, 0, 0, 0};
@@ -989,6 +1074,7 @@ inline f4 SampleSkyRadiance(const Ctx& c, f3 direction, uint32_t rayDepth)
     float intensity = 1.0f;
     if ((int32_t)rayDepth > 0) intensity = P.EnvironmentIntensity;     // SampleSkyRadiance(float3, int rayDepth)
     if (P.EnvironmentMode == PT_SKY_MODE_ENVIRONMENT) {
+        if (c.S->hasEnvironmentTexture) return EvalEnvMap(c, direction, intensity);   // EnvironmentSky :90-98
         f3 col = V3(P.EnvironmentColor[0], P.EnvironmentColor[1], P.EnvironmentColor[2]) * intensity;
         radiance = {col.x, col.y, col.z, pdf};
     } else if (P.EnvironmentMode == PT_SKY_MODE_BASIC) {
@@ -1047,17 +1133,34 @@ f3 DirectLight(Ctx& c, const Ray& ray, const RayHit& hit, const Material& mat, u
     f3 scatterPos = hit.position + hit.normal * PT_EPSILON;
 
     if (P.EnvironmentMode == 0) {
-        f3 Li = V3(P.EnvironmentColor[0], P.EnvironmentColor[1], P.EnvironmentColor[2]) * P.EnvironmentIntensity;
-        float lightPdf = 1.0f / (4.0f * PT_PI);
-        f3 lightDir = normalize(RandomCosineHemisphere(hit.normal, rng));
-        Ray shadowRay = {scatterPos, lightDir};
-        bool inShadow = ShadowRayIntersect(c, shadowRay);
-        if (!inShadow) {
-            float spdf = 0.0f;
-            f3 sf = EvalBRDF(mat, -ray.direction, hit.ffnormal, lightDir, spdf);
-            if (spdf > 0.0f) {
-                float misWeight = PowerHeuristic(lightPdf, spdf);
-                if (misWeight > 0.0f) Ld += misWeight * Li * sf / lightPdf;
+        if (c.S->hasEnvironmentTexture) {                                              // :125-141
+            f3 Li = V3(0.0f);
+            f4 dirPdf = SampleEnvMap(c, Li, rng);
+            f3 lightDir = V3(dirPdf.x, dirPdf.y, dirPdf.z);
+            float lightPdf = dirPdf.w;
+            Ray shadowRay = {scatterPos, lightDir};
+            bool inShadow = ShadowRayIntersect(c, shadowRay);
+            if (!inShadow) {
+                float spdf = 0.0f;
+                f3 sf = EvalBRDF(mat, -ray.direction, hit.ffnormal, lightDir, spdf);
+                if (spdf > 0.0f) {
+                    float misWeight = PowerHeuristic(lightPdf, spdf);
+                    if (misWeight > 0.0f) Ld += misWeight * Li * sf * P.EnvironmentIntensity / lightPdf;
+                }
+            }
+        } else {                                                                       // :143-157
+            f3 Li = V3(P.EnvironmentColor[0], P.EnvironmentColor[1], P.EnvironmentColor[2]) * P.EnvironmentIntensity;
+            float lightPdf = 1.0f / (4.0f * PT_PI);
+            f3 lightDir = normalize(RandomCosineHemisphere(hit.normal, rng));
+            Ray shadowRay = {scatterPos, lightDir};
+            bool inShadow = ShadowRayIntersect(c, shadowRay);
+            if (!inShadow) {
+                float spdf = 0.0f;
+                f3 sf = EvalBRDF(mat, -ray.direction, hit.ffnormal, lightDir, spdf);
+                if (spdf > 0.0f) {
+                    float misWeight = PowerHeuristic(lightPdf, spdf);
+                    if (misWeight > 0.0f) Ld += misWeight * Li * sf / lightPdf;
+                }
             }
         }
     }
@@ -1277,6 +1380,23 @@ SceneView MakeView(const PTSceneDesc* s)
     v.hasTlas = (s->features & PT_FEATURE_HAS_TLAS) != 0;
     v.tlas = s->tlasData; v.tlasFloats = s->tlasDataFloats; v.tlasIndexOffset = s->tlasIndexOffset;
     v.instances = (const PTGpuInstance*)s->gpuInstances; v.instanceCount = s->instanceCount;
+    v.hasEnvironmentTexture = (s->features & PT_FEATURE_HAS_ENVIRONMENT_TEXTURE) != 0;
+    v.envTexture = (const PTFloat4*)s->envTexture;
+    v.EnvironmentTextureWidth = (int32_t)s->envWidth; v.EnvironmentTextureHeight = (int32_t)s->envHeight;
+    v.EnvironmentCdfSum = 0.0f;
+    if (v.hasEnvironmentTexture) {
+        // PathTracer.cs:297-306 (OnEnvTexReadback): cdf[i] = sum of data[0..i].grayscale, float accumulator;
+        // UnityEngine.Color.grayscale = 0.299f * r + 0.587f * g + 0.114f * b
+        const size_t n = (size_t)s->envWidth * s->envHeight;
+        v.EnvironmentCDF.resize(n);
+        float sum = 0.0f;
+        for (size_t i = 0; i < n; i++) {
+            const PTFloat4& d = v.envTexture[i];
+            sum += 0.299f * d.x + 0.587f * d.y + 0.114f * d.z;
+            v.EnvironmentCDF[i] = sum;
+        }
+        v.EnvironmentCdfSum = sum;
+    }
     return v;
 }
 
@@ -1402,14 +1522,40 @@ float oracle_math(int fn, float x, float y)
     case 7: return pt_asin(x);
     case 8: return pt_sqrt(x);
     case 9: return pt_rcp(x);
+    case 10: return pt_atan2(x, y);
+    case 11: return pt_fmod(x, y);
     default: return 0.0f;
     }
 }
 
+float oracle_env_probe(const PTSceneDesc* scene, const PTFrameParams* params, int what, const float* in, uint64_t n, float* out)
+{
+    SceneView S = MakeView(scene);
+    if (!S.hasEnvironmentTexture) return 0.0f;
+    Ctx c;
+    c.S = &S; c.P = params; memset(&c.st, 0, sizeof(PTStats)); c.shadowAnyHit = false; c.nanRayEarlyOut = false; c.opt = nullptr;
+    for (uint64_t k = 0; k < n; k++) {
+        if (what == 0) out[k] = S.EnvironmentCDF[(size_t)in[k]];
+        else if (what == 1) { f2 uv = BinarySearch(S, in[k]); out[2 * k] = uv.x; out[2 * k + 1] = uv.y; }
+        else if (what == 2) {
+            f4 r = EvalEnvMap(c, V3(in[3 * k], in[3 * k + 1], in[3 * k + 2]), 1.0f);
+            out[4 * k] = r.x; out[4 * k + 1] = r.y; out[4 * k + 2] = r.z; out[4 * k + 3] = r.w;
+        } else if (what == 3) {
+            uint32_t rng = pt_asuint(in[k]);
+            f3 col = V3(0.0f);
+            f4 r = SampleEnvMap(c, col, rng);
+            float* o = out + 8 * k;
+            o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = r.w; o[4] = col.x; o[5] = col.y; o[6] = col.z; o[7] = 0.0f;
+        }
+    }
+    return S.EnvironmentCdfSum;
+}
+
 static Material MaterialFromData(const float* material, f3 V, f3 N, float eta)
 {
-    SceneView S;
-    memset(&S, 0, sizeof(S));
+    PTSceneDesc none;
+    memset(&none, 0, sizeof(none));
+    SceneView S = MakeView(&none);
     PTFrameParams P;
     memset(&P, 0, sizeof(P));
     Ctx c;

@@ -61,11 +61,19 @@ int oracle_trace(const PTSceneDesc* scene, const OracleRay* rays, uint64_t n, fl
 
 /* Scalar entry points for unit tests. */
 float    oracle_random_float(uint32_t* state);                       /* util/random.hlsl:12-16 */
-float    oracle_math(int fn, float x, float y);                      /* ptmi_math.h: 0 sin 1 cos 2 log 3 log2 4 exp2 5 pow 6 acos 7 asin 8 sqrt 9 rcp */
+float    oracle_math(int fn, float x, float y);                      /* ptmi_math.h: 0 sin 1 cos 2 log 3 log2 4 exp2 5 pow 6 acos 7 asin 8 sqrt 9 rcp 10 atan2(x = y-arg, y = x-arg) 11 fmod */
 /* Evaluates / samples the Disney BSDF in isolation (util/brdf.hlsl:114-340).
  * material: 32 floats of MaterialData (no textures); V, N, L world-space; returns f via out[0..2], pdf out[3]. */
 void     oracle_eval_brdf(const float* material, const float* V, const float* N, const float* L, float eta, float* out);
 void     oracle_sample_brdf(const float* material, const float* V, const float* N, float eta, uint32_t* rngState, float* outL, float* outFPdf);
+
+/* Environment-texture functions in isolation (util/sky.hlsl:7-88), `scene` with HAS_ENVIRONMENT_TEXTURE:
+ *   what 0: EnvironmentCDF[i] for i = in[k] (as float index)            -> out[k]            (n values)
+ *   what 1: BinarySearch(in[k])                                         -> out[2k..2k+1]     (uv)
+ *   what 2: EvalEnvMap(in[3k..3k+2], intensity 1)                       -> out[4k..4k+3]     (rgb, pdf)
+ *   what 3: SampleEnvMap with rngState = (uint)in[k] bits               -> out[8k..8k+7]     (dir xyz, pdf, colour rgb, 0)
+ * Returns EnvironmentCdfSum. */
+float    oracle_env_probe(const PTSceneDesc* scene, const PTFrameParams* params, int what, const float* in, uint64_t n, float* out);
 
 #ifdef __cplusplus
 }

@@ -70,6 +70,8 @@ def load_oracle():
         lib.oracle_eval_brdf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
         lib.oracle_sample_brdf.restype = None
         lib.oracle_sample_brdf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]
+        lib.oracle_env_probe.restype = C.c_float
+        lib.oracle_env_probe.argtypes = [C.POINTER(abi.PTSceneDesc), C.POINTER(abi.PTFrameParams), C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]
         _oracle = lib
     return _oracle
 
@@ -194,6 +196,10 @@ class SceneBuffers:
             d.tlasIndexOffset = tlas_index_offset
             d.instanceCount = self.inst.shape[0]
             d.gpuInstances = self.inst.ctypes.data
+        if scene.environment_texture is not None:
+            self.env = np.ascontiguousarray(scene.environment_texture, dtype=np.float32)
+            d.envTexture = self.env.ctypes.data
+            d.envHeight, d.envWidth = self.env.shape[:2]
         self.desc = d
 
 
@@ -243,3 +249,19 @@ def trace(buffers: SceneBuffers, rays: np.ndarray):
     rc = lib.oracle_trace(C.byref(buffers.desc), rays.ctypes.data, n, t.ctypes.data, prim.ctypes.data, steps.ctypes.data)
     assert rc == 0
     return t, prim, steps
+
+
+def env_probe(buffers: SceneBuffers, params, what: int, values: np.ndarray):
+    """oracle_env_probe: what 0 CDF[i], 1 BinarySearch(value), 2 EvalEnvMap(dir), 3 SampleEnvMap(rng state bits).
+    Returns (array, EnvironmentCdfSum)."""
+    lib = load_oracle()
+    per_in = {0: 1, 1: 1, 2: 3, 3: 1}[what]
+    per_out = {0: 1, 1: 2, 2: 4, 3: 8}[what]
+    if what == 3:
+        vin = np.ascontiguousarray(values, dtype=np.uint32).view(np.float32)
+    else:
+        vin = np.ascontiguousarray(values, dtype=np.float32)
+    n = vin.size // per_in
+    out = np.zeros((n, per_out), dtype=np.float32)
+    total = lib.oracle_env_probe(C.byref(buffers.desc), C.byref(params), what, vin.ctypes.data, n, out.ctypes.data)
+    return out, float(total)

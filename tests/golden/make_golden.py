@@ -91,6 +91,17 @@ def main():
                             stats=np.array([st.as_dict()[k] for k in sorted(st.as_dict())], dtype=np.uint64),
                             stat_names=np.array(sorted(st.as_dict())))
         print(f"frame_{name}: mean {img[..., :3].mean():.5f}")
+    # HAS_ENVIRONMENT_TEXTURE regression frame (synthetic HDR lat-long map, scenes.sky_environment)
+    sc = scenes.material_zoo(env_map=(64, 32))
+    nodes, tris = plugin.build_cwbvh(sc.vertices)
+    b = pyoracle.SceneBuffers(sc, nodes, tris)
+    w, hgt, spp, seed = 40, 24, 2, 0xE17
+    p = scenes.frame_params(sc, w, hgt, spp=spp, seed=seed)
+    img, st = pyoracle.render(b, p, threads=1)
+    np.savez_compressed(os.path.join(HERE, "frame_zoo_env.npz"), frame=img, width=w, height=hgt, spp=spp, seed=seed, env_w=64, env_h=32,
+                        stats=np.array([st.as_dict()[k] for k in sorted(st.as_dict())], dtype=np.uint64),
+                        stat_names=np.array(sorted(st.as_dict())))
+    print(f"frame_zoo_env: mean {img[..., :3].mean():.5f}")
 
 
 if __name__ == "__main__":

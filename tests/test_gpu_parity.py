@@ -67,6 +67,7 @@ def test_c1_cornell_256_1spp(oracle, schedule):
     ("zoo", {"basic_sky": True}, 96, 64, 2),
     ("sponza", {"tex_size": 32, "detail": 0.15}, 160, 96, 2),
     ("furnace", {}, 64, 64, 4),
+    ("zoo_env", {"env_map": (64, 32)}, 128, 80, 3),          # HAS_ENVIRONMENT_TEXTURE: importance-sampled lat-long map
 ])
 def test_small_scenes_bit_exact(oracle, name, kw, w, h, spp, schedule):
     s = scenes.make_scene(name, **kw)

@@ -46,6 +46,21 @@ def test_log_exp_pow_acos(lib):
     assert rel.max() < 5e-6                                        # pow = exp2(y*log2(x)), as HLSL defines it
 
 
+def test_atan2_fmod(lib):
+    """Environment-map lookups (util/sky.hlsl:46-53) need atan2 and fmod."""
+    rng = np.random.RandomState(3)
+    y = rng.normal(0, 1, 20000).astype(np.float32)
+    x = rng.normal(0, 1, 20000).astype(np.float32)
+    got = _apply(lib, 10, y, x)
+    assert np.abs(got - np.arctan2(y.astype(np.float64), x.astype(np.float64))).max() < 4e-7
+    f = lambda a, b: lib.oracle_math(10, a, b)
+    assert f(0.0, 0.0) == 0.0 and f(1.0, 0.0) == np.float32(np.pi / 2) and f(-1.0, 0.0) == np.float32(-np.pi / 2)
+    assert f(0.0, -1.0) == np.float32(np.pi) and f(0.0, 1.0) == 0.0 and np.isnan(f(float("nan"), 1.0))
+    a = rng.uniform(-3, 3, 5000).astype(np.float32)
+    m = _apply(lib, 11, a, np.ones_like(a))
+    assert np.array_equal(m, np.fmod(a, np.float32(1.0)))           # HLSL fmod keeps the sign of x, like C fmod
+
+
 def test_special_values(lib):
     f = lambda fn, x, y=0.0: lib.oracle_math(fn, x, y)
     assert f(2, 1.0) == 0.0 and f(4, 0.0) == 1.0 and f(6, 1.0) == 0.0

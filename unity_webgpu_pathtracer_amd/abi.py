@@ -54,6 +54,7 @@ assert BLAS_INSTANCE.itemsize == 192
 PT_FEATURE_HAS_LIGHTS = 0x1
 PT_FEATURE_HAS_TEXTURES = 0x2
 PT_FEATURE_HAS_TLAS = 0x4
+PT_FEATURE_HAS_ENVIRONMENT_TEXTURE = 0x8
 
 PT_OK = 0
 PT_ERR_INVALID_ARG = -1
@@ -75,6 +76,7 @@ class PTSceneDesc(C.Structure):
         ("tlasData", C.c_void_p), ("tlasDataFloats", C.c_uint64),
         ("tlasIndexOffset", C.c_uint32), ("instanceCount", C.c_uint32),
         ("gpuInstances", C.c_void_p),
+        ("envTexture", C.c_void_p), ("envWidth", C.c_uint32), ("envHeight", C.c_uint32),
     ]
 
 

@@ -41,7 +41,7 @@ struct EventPair { hipEvent_t start, stop; uint32_t launches; };
 struct PTContext {
     int device = 0;
     hipStream_t stream = nullptr;
-    DeviceBuffer nodes, tris, attrs, materials, lights, tex, tlas, instances;
+    DeviceBuffer nodes, tris, attrs, materials, lights, tex, tlas, instances, envTex, envCdf;
     DScene scene = {};
     bool hasScene = false;
     float4* frames[2] = {nullptr, nullptr};
@@ -269,7 +269,7 @@ PT_API int PTDestroy(PTContext* c)
     if (!c) return PT_OK;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
-    for (auto* b : {&c->nodes, &c->tris, &c->attrs, &c->materials, &c->lights, &c->tex, &c->tlas, &c->instances}) if (b->ptr) hipFree(b->ptr);
+    for (auto* b : {&c->nodes, &c->tris, &c->attrs, &c->materials, &c->lights, &c->tex, &c->tlas, &c->instances, &c->envTex, &c->envCdf}) if (b->ptr) hipFree(b->ptr);
     for (int i = 0; i < 2; i++) if (c->frames[i]) hipFree(c->frames[i]);
     if (c->dStats) hipFree(c->dStats);
     for (auto& set : c->sets) {
@@ -298,6 +298,9 @@ PT_API int PTSetScene(PTContext* c, const PTSceneDesc* s)
     if (!s->materials || s->materialCount == 0) return fail(PT_ERR_INVALID_ARG, "materials missing");
     if ((s->features & PT_FEATURE_HAS_LIGHTS) && (!s->lights || s->lightCount == 0)) return fail(PT_ERR_INVALID_ARG, "HAS_LIGHTS without lights");
     if ((s->features & PT_FEATURE_HAS_TEXTURES) && (!s->textureData || s->textureDataUints == 0)) return fail(PT_ERR_INVALID_ARG, "HAS_TEXTURES without texture data");
+    const bool envOn = (s->features & PT_FEATURE_HAS_ENVIRONMENT_TEXTURE) != 0;
+    if (envOn && (!s->envTexture || s->envWidth == 0 || s->envHeight == 0 || (uint64_t)s->envWidth * s->envHeight > 0x7FFFFFFFull))
+        return fail(PT_ERR_INVALID_ARG, "HAS_ENVIRONMENT_TEXTURE needs envTexture, envWidth, envHeight");
     HIP_TRY(hipSetDevice(c->device));
     for (auto& set : c->sets) if (set.stream) HIP_TRY(hipStreamSynchronize(set.stream));   // no pass may still read the old scene
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -312,6 +315,20 @@ PT_API int PTSetScene(PTContext* c, const PTSceneDesc* s)
     if (textures && (rc = upload(c, c->tex, s->textureData, (size_t)s->textureDataUints * 4))) return rc;
     if (tlasOn && (rc = upload(c, c->tlas, s->tlasData, (size_t)s->tlasDataFloats * 4))) return rc;
     if (tlasOn && (rc = upload(c, c->instances, s->gpuInstances, (size_t)s->instanceCount * 144))) return rc;
+    std::vector<float> cdf;
+    float cdfSum = 0.0f;
+    if (envOn) {
+        // OnEnvTexReadback (PathTracer.cs:297-306): running fp32 sum of Color.grayscale = 0.299 r + 0.587 g + 0.114 b
+        const size_t n = (size_t)s->envWidth * s->envHeight;
+        cdf.resize(n);
+        for (size_t i = 0; i < n; ++i) {
+            const float* px = s->envTexture + 4 * i;
+            cdfSum += 0.299f * px[0] + 0.587f * px[1] + 0.114f * px[2];
+            cdf[i] = cdfSum;
+        }
+        if ((rc = upload(c, c->envTex, s->envTexture, n * 16))) return rc;
+        if ((rc = upload(c, c->envCdf, cdf.data(), n * 4))) return rc;
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));      // inputs are borrowed for the duration of the call only
     c->scene.nodes = (const uint4*)c->nodes.ptr;
     c->scene.tris = (const float4*)c->tris.ptr;
@@ -327,6 +344,12 @@ PT_API int PTSetScene(PTContext* c, const PTSceneDesc* s)
     c->scene.instances = tlasOn ? (const float4*)c->instances.ptr : nullptr;
     c->scene.tlasIndexOffset = tlasOn ? s->tlasIndexOffset : 0u;
     c->scene.hasTlas = tlasOn ? 1u : 0u;
+    c->scene.envTex = envOn ? (const float4*)c->envTex.ptr : nullptr;
+    c->scene.envCdf = envOn ? (const float*)c->envCdf.ptr : nullptr;
+    c->scene.envW = envOn ? (int32_t)s->envWidth : 0;
+    c->scene.envH = envOn ? (int32_t)s->envHeight : 0;
+    c->scene.envCdfSum = cdfSum;
+    c->scene.hasEnvTex = envOn ? 1u : 0u;
     c->hasScene = true;
     return PT_OK;
 }

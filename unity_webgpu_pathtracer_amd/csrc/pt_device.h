@@ -92,6 +92,12 @@ struct DScene {
     const float4* instances;
     uint32_t tlasIndexOffset;
     uint32_t hasTlas;
+    // HAS_ENVIRONMENT_TEXTURE (util/sky.hlsl:7-88): RGBAFloat texels, running sum of their grayscale, its last value
+    const float4* envTex;
+    const float*  envCdf;
+    int32_t envW, envH;
+    float envCdfSum;
+    uint32_t hasEnvTex;
 };
 
 struct Counters {
@@ -965,14 +971,96 @@ PT_DEV v3 random_cosine_hemisphere(v3 normal, uint32_t& rng)
     return pt_sin(theta) * (pt_cos(phi) * onb.x + pt_sin(phi) * onb.y + pt_cos(theta) * onb.z);
 }
 
-// util/sky.hlsl:90-129 (colour / basic sky; the environment-texture half is not built: SURVEY.md §8f N4)
-PT_DEV v4 sample_sky_radiance(const PTFrameParams& P, v3 direction, uint32_t rayDepth)
+// ------------------------------------------------------------------------------------------
+// environment texture.  util/sky.hlsl:7-88
+// ------------------------------------------------------------------------------------------
+
+// EnvironmentTexture.SampleLevel(samplerEnvironmentTexture, uv, 0).rgb restated: bilinear, clamp addressing, texel
+// centres at (i + 0.5) / size, memory row r at v = 1 - (r + 0.5) / H (include/ptmi_plugin.h, PTSceneDesc.envTexture)
+PT_DEV v3 env_sample_level(const DScene& S, float u, float v)
+{
+    const float fx = u * (float)S.envW - 0.5f;
+    const float fy = (1.0f - v) * (float)S.envH - 0.5f;
+    const float x0f = pt_floor(fx), y0f = pt_floor(fy);
+    const float ax = fx - x0f, ay = fy - y0f;
+    int32_t x0 = pt_f2i(x0f), y0 = pt_f2i(y0f);
+    int32_t x1 = x0 < 2147483647 ? x0 + 1 : x0, y1 = y0 < 2147483647 ? y0 + 1 : y0;
+    const int32_t mx = S.envW - 1, my = S.envH - 1;
+    x0 = x0 < 0 ? 0 : (x0 > mx ? mx : x0); x1 = x1 < 0 ? 0 : (x1 > mx ? mx : x1);
+    y0 = y0 < 0 ? 0 : (y0 > my ? my : y0); y1 = y1 < 0 ? 0 : (y1 > my ? my : y1);
+    const float4 a = S.envTex[(size_t)y0 * S.envW + x0], b = S.envTex[(size_t)y0 * S.envW + x1];
+    const float4 c = S.envTex[(size_t)y1 * S.envW + x0], d = S.envTex[(size_t)y1 * S.envW + x1];
+    const v3 top = mk3(pt_lerp(a.x, b.x, ax), pt_lerp(a.y, b.y, ax), pt_lerp(a.z, b.z, ax));
+    const v3 bot = mk3(pt_lerp(c.x, d.x, ax), pt_lerp(c.y, d.y, ax), pt_lerp(c.z, d.z, ax));
+    return mk3(pt_lerp(top.x, bot.x, ay), pt_lerp(top.y, bot.y, ay), pt_lerp(top.z, bot.z, ay));
+}
+
+// BinarySearch :7-42: the row whose last CDF entry exceeds `value`, then the column inside that row
+PT_DEV void env_binary_search(const DScene& S, float value, float& u, float& v)
+{
+    int32_t lower = 0, upper = S.envH - 1;
+    while (lower < upper) {
+        const int32_t mid = (lower + upper) >> 1;
+        const int32_t idx = mid * S.envW + S.envW - 1;
+        if (value < S.envCdf[idx]) upper = mid; else lower = mid + 1;
+    }
+    const int32_t y = lower < 0 ? 0 : (lower > S.envH - 1 ? S.envH - 1 : lower);
+    lower = 0; upper = S.envW - 1;
+    while (lower < upper) {
+        const int32_t mid = (lower + upper) >> 1;
+        const int32_t idx = y * S.envW + mid;
+        if (value < S.envCdf[idx]) upper = mid; else lower = mid + 1;
+    }
+    const int32_t x = lower < 0 ? 0 : (lower > S.envW - 1 ? S.envW - 1 : lower);
+    u = (float)x / (float)S.envW;
+    v = (float)y / (float)S.envH;
+}
+
+// EvalEnvMap :44-64
+PT_DEV v4 eval_env_map(const DScene& S, const PTFrameParams& P, v3 r, float intensity)
+{
+    const float theta = pt_acos(pt_clamp(r.y, -1.0f, 1.0f));
+    const float r_atan = pt_atan2(r.z, r.x);
+    float u = (PT_PI + r_atan) * PT_INV_TWO_PI + P.EnvironmentMapRotation;
+    float v = (1.0f - theta * PT_INV_PI) + 0.0f;
+    u = pt_fmod(u, 1.0f);
+    v = pt_fmod(v, 1.0f);
+    if (u < 0.0f) u += 1.0f;
+    if (v < 0.0f) v += 1.0f;
+    const v3 color = env_sample_level(S, u, v);
+    float pdf = luminance3(color) / S.envCdfSum;
+    pdf = (pdf * (float)S.envW * (float)S.envH) / (PT_TWO_PI * PT_PI * pt_sin(theta));
+    const v3 c = color * intensity;
+    return {c.x, c.y, c.z, pdf};
+}
+
+// SampleEnvMap :66-88 (one RNG draw).  Returns (direction, pdf); `color` is the texel BEFORE any intensity.
+PT_DEV v4 sample_env_map(const DScene& S, const PTFrameParams& P, v3& color, uint32_t& rng)
+{
+    const float r = rnd(rng) * S.envCdfSum;
+    float u, v;
+    env_binary_search(S, r, u, v);
+    v = 1.0f - v;
+    color = env_sample_level(S, u, v);
+    float pdf = luminance3(color) / S.envCdfSum;
+    u -= P.EnvironmentMapRotation;
+    const float phi = u * PT_TWO_PI;
+    const float theta = v * PT_PI;
+    const float sinTheta = pt_sin(theta);
+    if (sinTheta == 0.0f) pdf = 0.0f;
+    return {-sinTheta * pt_cos(phi), pt_cos(theta), -sinTheta * pt_sin(phi),
+            (pdf * (float)S.envW * (float)S.envH) / (PT_TWO_PI * PT_PI * sinTheta)};
+}
+
+// util/sky.hlsl:90-129
+PT_DEV v4 sample_sky_radiance(const DScene& S, const PTFrameParams& P, v3 direction, uint32_t rayDepth)
 {
     v4 radiance = {0.0f, 0.0f, 0.0f, 0.0f};
     float pdf = 1.0f / (4.0f * PT_PI);
     float intensity = 1.0f;
     if ((int32_t)rayDepth > 0) intensity = P.EnvironmentIntensity;
     if (P.EnvironmentMode == PT_SKY_MODE_ENVIRONMENT) {
+        if (S.hasEnvTex) return eval_env_map(S, P, direction, intensity);          // EnvironmentSky :90-98
         v3 col = mk3(P.EnvironmentColor[0], P.EnvironmentColor[1], P.EnvironmentColor[2]) * intensity;
         radiance = {col.x, col.y, col.z, pdf};
     } else if (P.EnvironmentMode == PT_SKY_MODE_BASIC) {
@@ -996,24 +1084,34 @@ struct NeeRay { v3 dir; v3 contribution; uint32_t valid; };
 
 PT_DEV v3 nee_scatter_pos(const SurfHit& hit) { return hit.position + hit.normal * PT_EPSILON; }
 
-// environment half of DirectLight (:123-160, no environment texture)
-PT_DEV void nee_prepare_environment(const PTFrameParams& P, v3 rayDir, const SurfHit& hit, const Material& mat,
+// environment half of DirectLight (:123-160)
+PT_DEV void nee_prepare_environment(const DScene& S, const PTFrameParams& P, v3 rayDir, const SurfHit& hit, const Material& mat,
                                     uint32_t& rng, NeeRay& out)
 {
     out.valid = 0u;
     out.contribution = mk3(0.0f);
     if (P.EnvironmentMode != 0) return;
-    v3 Li = mk3(P.EnvironmentColor[0], P.EnvironmentColor[1], P.EnvironmentColor[2]) * P.EnvironmentIntensity;
-    float lightPdf = 1.0f / (4.0f * PT_PI);
-    v3 lightDir = normalize3(random_cosine_hemisphere(hit.normal, rng));
+    v3 Li, lightDir;
+    float lightPdf;
+    if (S.hasEnvTex) {                                   // HAS_ENVIRONMENT_TEXTURE :125-141
+        v4 dirPdf = sample_env_map(S, P, Li, rng);
+        lightDir = mk3(dirPdf.x, dirPdf.y, dirPdf.z);
+        lightPdf = dirPdf.w;
+    } else {                                             // :143-157
+        Li = mk3(P.EnvironmentColor[0], P.EnvironmentColor[1], P.EnvironmentColor[2]) * P.EnvironmentIntensity;
+        lightPdf = 1.0f / (4.0f * PT_PI);
+        lightDir = normalize3(random_cosine_hemisphere(hit.normal, rng));
+    }
     out.dir = lightDir;
     out.valid = 1u;
     float spdf = 0.0f;
     v3 sf = eval_brdf(mat, -rayDir, hit.ffnormal, lightDir, spdf);
     if (spdf > 0.0f) {
         float misWeight = power_heuristic(lightPdf, spdf);
-        if (misWeight > 0.0f) out.contribution = misWeight * Li * sf / lightPdf;
-        else out.valid = 2u;       // ray is traced (the reference traces before evaluating) but adds nothing
+        if (misWeight > 0.0f) {
+            if (S.hasEnvTex) out.contribution = misWeight * Li * sf * P.EnvironmentIntensity / lightPdf;
+            else out.contribution = misWeight * Li * sf / lightPdf;
+        } else out.valid = 2u;     // ray is traced (the reference traces before evaluating) but adds nothing
     } else out.valid = 2u;
 }
 
@@ -1232,7 +1330,7 @@ PT_DEV void path_step(const DScene& S, const PTFrameParams& P, PathRegs& r, cons
         intersect_lights<STATS>(S, r.ro, r.rd, hit, cn);
 
         if (!(hit.distance < PT_FAR_PLANE)) {
-            v4 sky = sample_sky_radiance(P, r.rd, r.depth);
+            v4 sky = sample_sky_radiance(S, P, r.rd, r.depth);
             float misWeight = 1.0f;
             if (r.depth > 0u) misWeight = power_heuristic(r.scatterPdf, sky.w);
             if (misWeight > 0.0f) r.radiance = r.radiance + misWeight * mk3(sky.x, sky.y, sky.z) * r.throughput;
@@ -1259,7 +1357,7 @@ PT_DEV void path_step(const DScene& S, const PTFrameParams& P, PathRegs& r, cons
                     scatterL = r.rd;                             // rayDepth-- then ++: depth unchanged (util/pathtrace.hlsl:85-88)
                 } else {
                     r.neeOrigin = nee_scatter_pos(hit);
-                    nee_prepare_environment(P, r.rd, hit, material, r.rng, r.env);
+                    nee_prepare_environment(S, P, r.rd, hit, material, r.rng, r.env);
                     nee_prepare_light<STATS>(S, r.rd, hit, material, r.neeOrigin, r.rng, r.light, cn);
                     r.pendThroughput = r.throughput;
                     r.hasPending = true;

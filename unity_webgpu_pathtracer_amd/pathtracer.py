@@ -93,6 +93,10 @@ class BVHScene:
             d.tlasIndexOffset = self.tlas_index_offset
             d.instanceCount = self.gpu_instances.shape[0]
             d.gpuInstances = self.gpu_instances.ctypes.data
+        if self.scene.environment_texture is not None:
+            self.env_texture = np.ascontiguousarray(self.scene.environment_texture, dtype=np.float32)
+            d.envTexture = self.env_texture.ctypes.data
+            d.envHeight, d.envWidth = self.env_texture.shape[:2]
         return d
 
     def PrepareShader(self, ctx):

@@ -59,6 +59,9 @@ class Scene:
     # mesh_ranges[i] = (first triangle, triangle count) of mesh i, instances[j] = (mesh index, localToWorld 4x4, material index)
     mesh_ranges: list = None
     instances: list = None
+    # HAS_ENVIRONMENT_TEXTURE (PathTracer.cs:32,119-137): (H, W, 4) float32, rows in readback order; None = colour / basic sky
+    environment_texture: np.ndarray = None
+    environment_map_rotation: float = 0.0
 
     @property
     def use_tlas(self):
@@ -77,6 +80,8 @@ class Scene:
             f |= abi.PT_FEATURE_HAS_TEXTURES
         if self.use_tlas:
             f |= abi.PT_FEATURE_HAS_TLAS
+        if self.environment_texture is not None:
+            f |= abi.PT_FEATURE_HAS_ENVIRONMENT_TEXTURE
         return f
 
 
@@ -132,7 +137,7 @@ def frame_params(scene: Scene, width: int, height: int, spp: int = 1, current_sa
     p.EnvironmentMode = scene.environment_mode
     p.EnvironmentIntensity = scene.environment_intensity
     p.EnvironmentColor[:] = [float(c) for c in scene.environment_color]
-    p.EnvironmentMapRotation = 0.0
+    p.EnvironmentMapRotation = scene.environment_map_rotation
     p.FocalLength = scene.camera.focal_length
     p.Aperture = scene.camera.aperture
     p.UseFireflyFilter = 1 if firefly else 0
@@ -674,7 +679,7 @@ def sponza_atrium(tex_size: int = 1024, detail: float = 1.0) -> Scene:
 # ---------------------------------------------------------------------------------------
 # zoo: every lobe / light type / alpha mode / texture slot / thin lens, small enough for the oracle
 # ---------------------------------------------------------------------------------------
-def material_zoo(tex_size: int = 32, basic_sky: bool = False) -> Scene:
+def material_zoo(tex_size: int = 32, basic_sky: bool = False, env_map=None) -> Scene:
     sb = SoupBuilder()
     S = tex_size
     images = [
@@ -713,11 +718,43 @@ def material_zoo(tex_size: int = 32, basic_sky: bool = False) -> Scene:
         pack_spot_light((3.0, 3.5, -2.5), (-0.6, -1.0, 0.5), 50.0, 30.0, (0.6, 0.8, 1.0), intensity=9.0, rng=15.0),
     ])
     cam = Camera(eye=(0.0, 2.2, -5.5), target=(0.0, 0.7, 0.5), vfov_deg=45.0, aperture=0.08, focal_length=6.0)
+    if env_map:
+        return Scene("zoo_env", verts, attrs, mats, lights, texture_data, cam, environment_mode=0,
+                     environment_color=(0.0, 0.0, 0.0, 1.0), environment_intensity=0.9,
+                     environment_texture=sky_environment(*env_map), environment_map_rotation=0.15)
     if basic_sky:
         return Scene("zoo_sky", verts, attrs, mats, lights, texture_data, cam, environment_mode=1,
                      environment_color=(0.0, 0.0, 0.0, 1.0), environment_intensity=0.8)
     return Scene("zoo", verts, attrs, mats, lights, texture_data, cam, environment_mode=0,
                  environment_color=(0.5, 0.6, 0.8, 1.0), environment_intensity=0.7)
+
+
+def sky_environment(width: int = 128, height: int = 64, sun_dir=(0.4, 0.55, -0.3), seed: int = 5) -> np.ndarray:
+    """A synthetic HDR lat-long environment (H, W, 4) float32: sky gradient, warm horizon band, dark ground, a small very
+    bright sun and a few noise clouds.  Stands in for PathTracer.environmentTexture (PathTracer.cs:32); rows are in the
+    order the path tracer consumes them (include/ptmi_plugin.h, PTSceneDesc.envTexture): row r is at v = 1 - (r + 0.5)/H."""
+    r = (np.arange(height, dtype=np.float64) + 0.5) / height
+    c = (np.arange(width, dtype=np.float64) + 0.5) / width
+    v = 1.0 - r[:, None]                                   # uv.y of the row
+    u = np.broadcast_to(c[None, :], (height, width))
+    # inverse of EvalEnvMap's mapping (sky.hlsl:46-48): theta = (1 - v) * pi, atan2(z, x) = u * 2pi - pi
+    theta = (1.0 - v) * np.pi
+    phi = u * 2.0 * np.pi - np.pi
+    d = np.stack([np.sin(theta) * np.cos(phi), np.cos(theta) * np.ones_like(phi), np.sin(theta) * np.sin(phi)], axis=-1)
+    up = np.clip(d[..., 1], 0.0, 1.0)
+    sky = (1.0 - up)[..., None] * np.array([0.9, 0.75, 0.6]) + up[..., None] * np.array([0.15, 0.35, 0.9])
+    ground = np.array([0.08, 0.07, 0.06])
+    img = np.where((d[..., 1] >= 0.0)[..., None], sky, ground)
+    s = np.asarray(sun_dir, dtype=np.float64)
+    s = s / np.linalg.norm(s)
+    cosang = np.clip((d * s).sum(-1), -1.0, 1.0)
+    img = img + (np.exp((cosang - 1.0) * 900.0) * 400.0)[..., None] * np.array([1.0, 0.9, 0.7])
+    clouds = value_noise3(np.stack([u * 6.0, np.broadcast_to(v, u.shape) * 3.0, np.zeros_like(u)], axis=-1).reshape(-1, 3),
+                          seed=seed, octaves=3, frequency=1.5).reshape(height, width)
+    img = img + (np.clip(clouds, 0.0, 1.0) * (d[..., 1] > 0.05))[..., None] * 0.6
+    out = np.ones((height, width, 4), dtype=F32)
+    out[..., :3] = img.astype(F32)
+    return out
 
 
 def furnace(albedo: float = 0.8) -> Scene:
@@ -838,6 +875,7 @@ SCENES = {
     "bunny": bunny_box,
     "sponza": sponza_atrium,
     "zoo": material_zoo,
+    "zoo_env": lambda **kw: material_zoo(env_map=kw.pop("env_map", (128, 64)), **kw),
     "furnace": furnace,
     "instanced": instanced_scene,
 }
