@@ -201,6 +201,19 @@ PT_API int PTSynchronize(PTContext* ctx);
 PT_API int PTReadback(PTContext* ctx, float* dstRGBA, uint64_t dstFloats);
 /* Device pointer of internal frame `which` (0/1) or of the current Output frame (-1). */
 PT_API void* PTGetFramePointer(PTContext* ctx, int which);
+/* The presentation blit (Assets/Resources/Presentation.shader:36-73 with util/tonemap.hlsl), i.e. the uniforms
+ * PathTracer.cs:255-264 sets on _presentationMaterial.  Mode = TonemapMode (PathTracer.cs:8-14). */
+typedef struct PTPresentParams {
+    uint32_t OutputWidth, OutputHeight;
+    int32_t  Mode;            /* 0 none, 1 ACES, 2 Filmic, 3 Reinhard, 4 Lottes */
+    int32_t  sRGB;            /* LinearToSrgb after the operator */
+    float    Exposure, Brightness, Contrast, Saturation, Vignette;
+} PTPresentParams;
+/* dst = present(src): both DEVICE pointers to OutputWidth*OutputHeight float4; src == NULL reads the context's current
+ * Output frame.  Ordered on the context stream after every pass launched so far (cmd.Blit after DispatchCompute). */
+PT_API int PTPresent(PTContext* ctx, const PTPresentParams* params, const void* dSrc, void* dDst);
+/* Presents the context's current Output frame into host memory (width*height float4). */
+PT_API int PTPresentToHost(PTContext* ctx, const PTPresentParams* params, float* dstRGBA, uint64_t dstFloats);
 /* The hipStream_t (as void*) all passes of this context are launched on. */
 PT_API void* PTGetStream(PTContext* ctx);
 

@@ -1551,6 +1551,83 @@ float oracle_env_probe(const PTSceneDesc* scene, const PTFrameParams* params, in
     return S.EnvironmentCdfSum;
 }
 
+// ------------------------------------------------------------------------------------------
+// util/tonemap.hlsl + Presentation.shader FragBlit
+// ------------------------------------------------------------------------------------------
+namespace {
+inline f3 pow_f3(f3 v, float e) { return V3(pt_pow(v.x, e), pt_pow(v.y, e), pt_pow(v.z, e)); }
+inline f3 lerp_f3(f3 x, f3 y, f3 s) { return x + s * (y - x); }
+inline f3 greaterThan(f3 a, f3 b) { return V3(a.x > b.x ? 1.0f : 0.0f, a.y > b.y ? 1.0f : 0.0f, a.z > b.z ? 1.0f : 0.0f); }   // util/common.hlsl:269-272
+inline f3 saturate3(f3 v) { return V3(pt_saturate(v.x), pt_saturate(v.y), pt_saturate(v.z)); }
+inline f3 mul3x3(const float* m, f3 c)          // mul(float3x3 M, float3 v): rows dotted with v
+{
+    return V3(dot(V3(m[0], m[1], m[2]), c), dot(V3(m[3], m[4], m[5]), c), dot(V3(m[6], m[7], m[8]), c));
+}
+
+inline f3 LinearToSrgb(f3 rgb)                                                         // tonemap.hlsl:6-11
+{
+    f3 low = rgb * 12.92f;
+    f3 high = pow_f3(rgb, 1.0f / 2.4f) * 1.055f - V3(0.055f);
+    return lerp_f3(low, high, greaterThan(rgb, V3(0.0031308f)));
+}
+
+inline f3 ACES(f3 color)                                                               // :21-46
+{
+    static const float ACESInputMat[9] = {0.59719f, 0.35458f, 0.04823f, 0.07600f, 0.90834f, 0.01566f, 0.02840f, 0.13383f, 0.83777f};
+    static const float ACESOutputMat[9] = {1.60475f, -0.53108f, -0.07367f, -0.10208f, 1.10813f, -0.00605f, -0.00327f, -0.07276f, 1.07602f};
+    color = mul3x3(ACESInputMat, color);
+    f3 a = color * (color + 0.0245786f) - V3(0.000090537f);
+    f3 b = color * (0.983729f * color + 0.4329510f) + 0.238081f;
+    color = a / b;
+    return mul3x3(ACESOutputMat, color);
+}
+
+inline f3 Filmic(f3 x)                                                                 // :49-54
+{
+    f3 X = V3(pt_max(0.0f, x.x - 0.004f), pt_max(0.0f, x.y - 0.004f), pt_max(0.0f, x.z - 0.004f));
+    f3 result = (X * (6.2f * X + 0.5f)) / (X * (6.2f * X + 1.7f) + 0.06f);
+    return pow_f3(result, 2.2f);
+}
+
+inline f3 Lottes(f3 x)                                                                 // :57-74
+{
+    const float a = 1.6f, d = 0.977f, hdrMax = 8.0f, midIn = 0.18f, midOut = 0.267f;
+    float b = (-pt_pow(midIn, a) + pt_pow(hdrMax, a) * midOut) / ((pt_pow(hdrMax, a * d) - pt_pow(midIn, a * d)) * midOut);
+    float c = (pt_pow(hdrMax, a * d) * pt_pow(midIn, a) - pt_pow(hdrMax, a) * pt_pow(midIn, a * d) * midOut) /
+              ((pt_pow(hdrMax, a * d) - pt_pow(midIn, a * d)) * midOut);
+    return pow_f3(x, a) / (pow_f3(x, a * d) * b + c);
+}
+
+inline f3 Reinhard(f3 x) { return x / (V3(1.0f) + x); }                                // :76-79
+}
+
+int oracle_present(const PTPresentParams* Q, const float* src, float* dst)             // Presentation.shader:36-73
+{
+    if (!Q || !src || !dst) return -1;
+    for (uint32_t y = 0; y < Q->OutputHeight; y++)
+        for (uint32_t x = 0; x < Q->OutputWidth; x++) {
+            const size_t i = (size_t)y * Q->OutputWidth + x;
+            f3 color = V3(src[4 * i], src[4 * i + 1], src[4 * i + 2]);      // tex2D(_MainTex, i.uv) at the pixel centre
+            color = color * Q->Exposure;
+            switch (Q->Mode) {
+            case 1: color = ACES(color); break;
+            case 2: color = Filmic(color); break;
+            case 3: color = Reinhard(color); break;
+            case 4: color = Lottes(color); break;
+            }
+            if (Q->sRGB) color = LinearToSrgb(color);
+            color = saturate3(lerp_f3(V3(0.5f), color, V3(Q->Contrast)));
+            color = pow_f3(color, 1.0f / Q->Brightness);
+            f3 l = V3(Luminance(color));
+            color = lerp_f3(l, color, V3(Q->Saturation));
+            f2 uv = {((float)x + 0.5f) / (float)Q->OutputWidth, ((float)y + 0.5f) / (float)Q->OutputHeight};
+            f2 centerUv = {(uv.x - 0.5f) * 2.0f, (uv.y - 0.5f) * 2.0f};
+            color = color * (1.0f - (centerUv.x * centerUv.x + centerUv.y * centerUv.y) * Q->Vignette);
+            dst[4 * i] = color.x; dst[4 * i + 1] = color.y; dst[4 * i + 2] = color.z; dst[4 * i + 3] = 1.0f;
+        }
+    return 0;
+}
+
 static Material MaterialFromData(const float* material, f3 V, f3 N, float eta)
 {
     PTSceneDesc none;

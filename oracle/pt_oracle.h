@@ -75,6 +75,9 @@ void     oracle_sample_brdf(const float* material, const float* V, const float* 
  * Returns EnvironmentCdfSum. */
 float    oracle_env_probe(const PTSceneDesc* scene, const PTFrameParams* params, int what, const float* in, uint64_t n, float* out);
 
+/* The presentation blit, Assets/Resources/Presentation.shader:36-73 + util/tonemap.hlsl, one pixel after the other. */
+int      oracle_present(const PTPresentParams* params, const float* srcRGBA, float* dstRGBA);
+
 #ifdef __cplusplus
 }
 #endif

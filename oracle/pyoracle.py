@@ -70,6 +70,8 @@ def load_oracle():
         lib.oracle_eval_brdf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
         lib.oracle_sample_brdf.restype = None
         lib.oracle_sample_brdf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]
+        lib.oracle_present.restype = C.c_int
+        lib.oracle_present.argtypes = [C.POINTER(abi.PTPresentParams), C.c_void_p, C.c_void_p]
         lib.oracle_env_probe.restype = C.c_float
         lib.oracle_env_probe.argtypes = [C.POINTER(abi.PTSceneDesc), C.POINTER(abi.PTFrameParams), C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]
         _oracle = lib
@@ -265,3 +267,12 @@ def env_probe(buffers: SceneBuffers, params, what: int, values: np.ndarray):
     out = np.zeros((n, per_out), dtype=np.float32)
     total = lib.oracle_env_probe(C.byref(buffers.desc), C.byref(params), what, vin.ctypes.data, n, out.ctypes.data)
     return out, float(total)
+
+
+def present(params, frame: np.ndarray) -> np.ndarray:
+    """oracle_present: Presentation.shader over a linear (H, W, 4) float32 frame."""
+    src = np.ascontiguousarray(frame, dtype=np.float32)
+    dst = np.empty_like(src)
+    rc = load_oracle().oracle_present(C.byref(params), src.ctypes.data, dst.ctypes.data)
+    assert rc == 0
+    return dst

@@ -46,9 +46,9 @@ def test_struct_sizes_match_c_headers():
     #include <stdio.h>
     #include "ptmi_plugin.h"
     int main(void) {
-      printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(PTSceneDesc), sizeof(PTFrameParams), sizeof(PTStats),
+      printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(PTSceneDesc), sizeof(PTFrameParams), sizeof(PTStats),
              sizeof(PTTimings), sizeof(PTCwbvhNode), sizeof(PTCwbvhTri), sizeof(PTTriangleAttributes), sizeof(PTMaterialData),
-             sizeof(PTLight), sizeof(PTTlasNode), sizeof(PTBlasInstance), sizeof(PTGpuInstance));
+             sizeof(PTLight), sizeof(PTTlasNode), sizeof(PTBlasInstance), sizeof(PTGpuInstance), sizeof(PTPresentParams));
       return 0; }
     """
     with tempfile.TemporaryDirectory() as d:
@@ -61,7 +61,8 @@ def test_struct_sizes_match_c_headers():
     assert sizes[1] == C.sizeof(abi.PTFrameParams)
     assert sizes[2] == C.sizeof(abi.PTStats) == 16 * 8
     assert sizes[3] == C.sizeof(abi.PTTimings)
-    assert sizes[4:] == [80, 48, 128, 128, 64, 64, 192, 144]
+    assert sizes[4:12] == [80, 48, 128, 128, 64, 64, 192, 144]
+    assert sizes[12] == C.sizeof(abi.PTPresentParams) == 36
     assert abi.CWBVH_NODE.itemsize == 80 and abi.TRI_ATTR.itemsize == 128 and abi.BLAS_INSTANCE.itemsize == 192
 
 

@@ -130,6 +130,16 @@ class PTStats(C.Structure):
                    + 64 * self.tlasNodeVisits + 144 * self.instanceVisits)
 
 
+class PTPresentParams(C.Structure):
+    """Presentation.shader uniforms (PathTracer.cs:255-264); defaults = the inspector defaults (PathTracer.cs:41-48)."""
+    _fields_ = [("OutputWidth", C.c_uint32), ("OutputHeight", C.c_uint32), ("Mode", C.c_int32), ("sRGB", C.c_int32),
+                ("Exposure", C.c_float), ("Brightness", C.c_float), ("Contrast", C.c_float), ("Saturation", C.c_float),
+                ("Vignette", C.c_float)]
+
+
+TONEMAP_NONE, TONEMAP_ACES, TONEMAP_FILMIC, TONEMAP_REINHARD, TONEMAP_LOTTES = range(5)      # PathTracer.cs:8-14
+
+
 class PTTimings(C.Structure):
     _fields_ = [("passes", C.c_uint64), ("kernelMsTotal", C.c_double),
                 ("kernelMsLast", C.c_double), ("kernelLaunches", C.c_uint64)]

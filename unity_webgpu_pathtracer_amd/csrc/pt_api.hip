@@ -42,6 +42,8 @@ struct PTContext {
     int device = 0;
     hipStream_t stream = nullptr;
     DeviceBuffer nodes, tris, attrs, materials, lights, tex, tlas, instances, envTex, envCdf;
+    void* present = nullptr;                    // PTPresentToHost staging frame
+    size_t presentBytes = 0;
     DScene scene = {};
     bool hasScene = false;
     float4* frames[2] = {nullptr, nullptr};
@@ -272,6 +274,7 @@ PT_API int PTDestroy(PTContext* c)
     for (auto* b : {&c->nodes, &c->tris, &c->attrs, &c->materials, &c->lights, &c->tex, &c->tlas, &c->instances, &c->envTex, &c->envCdf}) if (b->ptr) hipFree(b->ptr);
     for (int i = 0; i < 2; i++) if (c->frames[i]) hipFree(c->frames[i]);
     if (c->dStats) hipFree(c->dStats);
+    if (c->present) hipFree(c->present);
     for (auto& set : c->sets) {
         if (set.stream) { hipStreamSynchronize(set.stream); hipStreamDestroy(set.stream); }
         if (set.arena) hipFree(set.arena);
@@ -396,6 +399,39 @@ PT_API int PTReadback(PTContext* c, float* dst, uint64_t dstFloats)
     if (dstFloats < need) return fail(PT_ERR_INVALID_ARG, "destination too small");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemcpyAsync(dst, c->frames[c->cur], need * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+PT_API int PTPresent(PTContext* c, const PTPresentParams* q, const void* dSrc, void* dDst)
+{
+    if (!c || !q || !dDst) return fail(PT_ERR_INVALID_ARG, "ctx/params/dst == NULL");
+    if (q->OutputWidth == 0 || q->OutputHeight == 0 || (uint64_t)q->OutputWidth * q->OutputHeight > 0x7FFFFFFFull / 4)
+        return fail(PT_ERR_INVALID_ARG, "bad presentation size");
+    if (!dSrc) {
+        if (!c->frames[0]) return fail(PT_ERR_INVALID_ARG, "no frame rendered yet");
+        if (q->OutputWidth != c->frameW || q->OutputHeight != c->frameH) return fail(PT_ERR_INVALID_ARG, "presentation size differs from the rendered frame");
+        dSrc = c->frames[c->cur];
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(pt_launch_present(*q, (const float4*)dSrc, (float4*)dDst, c->stream));
+    return PT_OK;
+}
+
+PT_API int PTPresentToHost(PTContext* c, const PTPresentParams* q, float* dst, uint64_t dstFloats)
+{
+    if (!c || !q || !dst) return fail(PT_ERR_INVALID_ARG, "ctx/params/dst == NULL");
+    const uint64_t need = (uint64_t)q->OutputWidth * q->OutputHeight * 4;
+    if (dstFloats < need) return fail(PT_ERR_INVALID_ARG, "destination too small");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->presentBytes < need * sizeof(float)) {
+        if (c->present) { hipFree(c->present); c->present = nullptr; c->presentBytes = 0; }
+        HIP_TRY(hipMalloc(&c->present, need * sizeof(float)));
+        c->presentBytes = need * sizeof(float);
+    }
+    int rc = PTPresent(c, q, nullptr, c->present);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(dst, c->present, need * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return PT_OK;
 }

@@ -14,6 +14,8 @@ struct PTTileMap {
 hipError_t pt_launch_megakernel(const DScene& S, const PTFrameParams& P, const float4* accumulated, float4* output,
                                 const PTTileMap& tm, unsigned long long* gstats, bool fullStats, hipStream_t stream);
 
+hipError_t pt_launch_present(const PTPresentParams& Q, const float4* src, float4* dst, hipStream_t stream);
+
 // ---- schedule 1 (wavefront): slot-indexed path state in HBM (see pt_wavefront.hip) ----
 struct PTWfBuffers {
     uint32_t* flags;            // [numSlots] packed state word

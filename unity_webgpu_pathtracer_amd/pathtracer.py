@@ -122,6 +122,10 @@ class PathTracer:
         self.fireflyFilter = fireflyFilter
         self.maxFireflyLuminance = maxFireflyLuminance
         self.reference_dispatch = reference_dispatch
+        # tonemapping settings (PathTracer.cs:41-48)
+        self.tonemapMode = abi.TONEMAP_LOTTES
+        self.sRGB = False
+        self.exposure, self.brightness, self.contrast, self.saturation, self.vignette = 1.0, 1.0, 1.0, 1.0, 0.0
         self._currentSample = 0
         ctx = C.c_void_p()
         plugin.check(self.lib.PTCreate(device, C.byref(ctx)))
@@ -217,6 +221,25 @@ class PathTracer:
 
     def reset_timings(self):
         plugin.check(self.lib.PTResetTimings(self.ctx))
+
+    # ---- PathTracer.cs:255-266: the presentation blit of _outputRT[_currentRT]
+    def present_params(self) -> abi.PTPresentParams:
+        q = abi.PTPresentParams()
+        q.OutputWidth, q.OutputHeight = self.width, self.height
+        q.Mode, q.sRGB = int(self.tonemapMode), 1 if self.sRGB else 0
+        q.Exposure, q.Brightness, q.Contrast, q.Saturation, q.Vignette = (self.exposure, self.brightness, self.contrast,
+                                                                          self.saturation, self.vignette)
+        return q
+
+    def present(self, q: abi.PTPresentParams = None) -> np.ndarray:
+        """The displayable image of the current Output frame, (H, W, 4) float32."""
+        q = q or self.present_params()
+        out = np.empty((q.OutputHeight, q.OutputWidth, 4), dtype=np.float32)
+        plugin.check(self.lib.PTPresentToHost(self.ctx, C.byref(q), out.ctypes.data_as(C.c_void_p), out.size))
+        return out
+
+    def present_to(self, q: abi.PTPresentParams, d_src: int, d_dst: int):
+        plugin.check(self.lib.PTPresent(self.ctx, C.byref(q), C.c_void_p(d_src) if d_src else None, C.c_void_p(d_dst)))
 
     def set_schedule(self, schedule: int):
         plugin.check(self.lib.PTSetSchedule(self.ctx, schedule))

@@ -63,6 +63,8 @@ def load_library():
         "PTGetFramePointer": (vp, [vp, i32]), "PTGetStream": (vp, [vp]),
         "PTSetStatsLevel": (i32, [vp, i32]), "PTGetStats": (i32, [vp, C.POINTER(abi.PTStats)]), "PTResetStats": (i32, [vp]),
         "PTSetProfiling": (i32, [vp, i32]), "PTGetTimings": (i32, [vp, C.POINTER(abi.PTTimings)]), "PTResetTimings": (i32, [vp]),
+        "PTPresent": (i32, [vp, C.POINTER(abi.PTPresentParams), vp, vp]),
+        "PTPresentToHost": (i32, [vp, C.POINTER(abi.PTPresentParams), vp, C.c_uint64]),
         "PTSetSchedule": (i32, [vp, i32]), "PTGetSchedule": (i32, [vp]), "PTSetWavefrontIterations": (i32, [vp, i32]),
         "PTGetLastError": (C.c_char_p, []), "PTGetVersion": (i32, []),
     }
@@ -79,7 +81,7 @@ EXPORTED_SYMBOLS = [
     "BuildTLAS", "DestroyTLAS", "IsTLASReady", "GetTLASNodesSize", "GetTLASData",
     "PTCreate", "PTDestroy", "PTSetScene", "PTSetTileOwnership", "PTRenderPass", "PTFlipFrames", "PTResetFrames",
     "PTRenderPassTo", "PTSynchronize", "PTReadback", "PTGetFramePointer", "PTGetStream", "PTSetStatsLevel", "PTGetStats",
-    "PTResetStats", "PTSetProfiling", "PTGetTimings", "PTResetTimings", "PTSetSchedule", "PTGetSchedule", "PTSetWavefrontIterations",
+    "PTResetStats", "PTSetProfiling", "PTGetTimings", "PTResetTimings", "PTPresent", "PTPresentToHost", "PTSetSchedule", "PTGetSchedule", "PTSetWavefrontIterations",
     "PTGetLastError", "PTGetVersion",
 ]
 
