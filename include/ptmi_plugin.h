@@ -214,6 +214,37 @@ typedef struct PTPresentParams {
 PT_API int PTPresent(PTContext* ctx, const PTPresentParams* params, const void* dSrc, void* dDst);
 /* Presents the context's current Output frame into host memory (width*height float4). */
 PT_API int PTPresentToHost(PTContext* ctx, const PTPresentParams* params, float* dstRGBA, uint64_t dstFloats);
+/* ---- scene ingestion: the two compute shaders that turn Unity meshes / textures into the path
+ * tracer's buffers, run on the MI355X.  Inputs and outputs are HOST memory; the work is staged through HBM. ---- */
+
+/* One Dispatch of Assets/Resources/MeshProcessing.compute as BVHScene.ProcessMeshes sets it up (BVHScene.cs:489-553). */
+#define PT_MESH_HAS_32_BIT_INDICES 0x1u   /* mesh.indexFormat == UInt32 (only read when indexBuffer != NULL) */
+#define PT_MESH_HAS_NORMALS        0x2u
+#define PT_MESH_HAS_TANGENTS       0x4u
+#define PT_MESH_HAS_UVS            0x8u
+typedef struct PTMeshDesc {
+    const void* vertexBuffer;  uint64_t vertexBufferBytes;   /* mesh.GetVertexBuffer(0): interleaved, fp32 attributes      */
+    const void* indexBuffer;   uint64_t indexBufferBytes;    /* mesh.GetIndexBuffer(); NULL = HAS_INDEX_BUFFER off          */
+    uint32_t VertexStride, PositionOffset, NormalOffset, TangentOffset, UVOffset;   /* bytes (Utilities.FindVertexAttribute) */
+    uint32_t MaterialIndex;
+    uint32_t TriangleCount, OutputTriangleStart;
+    float    LocalToWorld[16], WorldToLocal[16];              /* Unity Matrix4x4 memory order, as in PTFrameParams          */
+    uint32_t flags;            uint32_t _pad;                 /* PT_MESH_HAS_*                                                */
+} PTMeshDesc;
+/* ProcessMeshes + the readback (BVHScene.cs:429-560): runs the kernel once per mesh and returns
+ * VertexPositionBuffer (3 float4 per triangle, w = 0: BuildBVH's input) and TriangleAttributesBuffer (PTTriangleAttributes
+ * per triangle).  totalTriangles = the size of both outputs; every mesh writes [OutputTriangleStart, +TriangleCount). */
+PT_API int PTProcessMeshes(PTContext* ctx, const PTMeshDesc* meshes, uint32_t meshCount, uint32_t totalTriangles,
+                           float* outVertexPositions, void* outTriangleAttributes);
+
+/* The texture loop of BVHScene.UpdateMaterialData (BVHScene.cs:386-417) over Assets/Resources/CopyTextureData.compute:
+ * every texture (RGBA fp32 texels, row y = Texture.Load(int3(x, y, 0))) becomes a {w, h, offset, 0} descriptor and w*h RGBA8
+ * words.  outTextureData must hold 4*count + sum(w*h) uints. */
+typedef struct PTTextureDesc {
+    const float* texels;  uint32_t width, height;  int32_t hasAlpha;  uint32_t _pad;
+} PTTextureDesc;
+PT_API int PTCopyTextureData(PTContext* ctx, const PTTextureDesc* textures, uint32_t count, uint32_t* outTextureData, uint64_t outUints);
+
 /* The hipStream_t (as void*) all passes of this context are launched on. */
 PT_API void* PTGetStream(PTContext* ctx);
 

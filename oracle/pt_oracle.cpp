@@ -1552,6 +1552,128 @@ float oracle_env_probe(const PTSceneDesc* scene, const PTFrameParams* params, in
 }
 
 // ------------------------------------------------------------------------------------------
+// MeshProcessing.compute / CopyTextureData.compute
+// ------------------------------------------------------------------------------------------
+namespace {
+struct ByteAddressBuffer {
+    const uint8_t* p;
+    uint32_t Load(uint32_t off) const { uint32_t v; memcpy(&v, p + off, 4); return v; }
+    f3 LoadFloat3(uint32_t off) const { return V3(pt_asfloat(Load(off)), pt_asfloat(Load(off + 4)), pt_asfloat(Load(off + 8))); }
+};
+// float4x4 in Unity memory order: M(r, c) = m[c * 4 + r]
+inline f4 mulMV(const float* m, f4 v)          // mul(M, v)
+{
+    f4 r;
+    r.x = m[0] * v.x + m[4] * v.y + m[8] * v.z + m[12] * v.w;
+    r.y = m[1] * v.x + m[5] * v.y + m[9] * v.z + m[13] * v.w;
+    r.z = m[2] * v.x + m[6] * v.y + m[10] * v.z + m[14] * v.w;
+    r.w = m[3] * v.x + m[7] * v.y + m[11] * v.z + m[15] * v.w;
+    return r;
+}
+inline f4 mulVM(f4 v, const float* m)          // mul(v, M)
+{
+    f4 r;
+    r.x = v.x * m[0] + v.y * m[1] + v.z * m[2] + v.w * m[3];
+    r.y = v.x * m[4] + v.y * m[5] + v.z * m[6] + v.w * m[7];
+    r.z = v.x * m[8] + v.y * m[9] + v.z * m[10] + v.w * m[11];
+    r.w = v.x * m[12] + v.y * m[13] + v.z * m[14] + v.w * m[15];
+    return r;
+}
+inline f3 xyz(f4 v) { return V3(v.x, v.y, v.z); }
+}
+
+int oracle_process_mesh(const PTMeshDesc* M, float* vertexPositionBuffer, void* triangleAttributesBuffer)   // MeshProcessing.compute:59-139
+{
+    if (!M || !vertexPositionBuffer || !triangleAttributesBuffer) return -1;
+    ByteAddressBuffer VertexBuffer = {(const uint8_t*)M->vertexBuffer};
+    std::vector<uint8_t> paddedIndices;
+    ByteAddressBuffer IndexBuffer = {nullptr};
+    if (M->indexBuffer) {                        // Load2 on the last odd triangle reads one word past the 16-bit data
+        paddedIndices.assign((size_t)M->indexBufferBytes + 8, 0);
+        memcpy(paddedIndices.data(), M->indexBuffer, (size_t)M->indexBufferBytes);
+        IndexBuffer.p = paddedIndices.data();
+    }
+    PTTriangleAttributes* out = (PTTriangleAttributes*)triangleAttributesBuffer;
+    for (uint32_t triIndex = 0; triIndex < M->TriangleCount; triIndex++) {
+        uint32_t vertIndices[3];
+        if (M->indexBuffer) {
+            if (M->flags & PT_MESH_HAS_32_BIT_INDICES) {
+                uint32_t byteOffset = triIndex * (3 * 4);
+                for (int k = 0; k < 3; k++) vertIndices[k] = IndexBuffer.Load(byteOffset + 4 * k);
+            } else {
+                uint32_t byteOffset = triIndex * (3 * 2);
+                uint32_t alignedOffset = byteOffset & ~3u;
+                uint32_t px = IndexBuffer.Load(alignedOffset), py = IndexBuffer.Load(alignedOffset + 4);
+                uint32_t offsetInWord = byteOffset % 4;
+                vertIndices[0] = (offsetInWord == 0) ? (px & 0xFFFF) : (px >> 16);
+                vertIndices[1] = (offsetInWord == 0) ? (px >> 16) : (py & 0xFFFF);
+                vertIndices[2] = (offsetInWord == 0) ? (py & 0xFFFF) : (py >> 16);
+            }
+        } else {
+            vertIndices[0] = triIndex * 3; vertIndices[1] = triIndex * 3 + 1; vertIndices[2] = triIndex * 3 + 2;
+        }
+        int writeTriIndex = (int)(M->OutputTriangleStart + triIndex);
+        int writeIndex = writeTriIndex * 3;
+        PTTriangleAttributes attr;
+        memset(&attr, 0, sizeof(attr));
+        float* nrm[3] = {attr.normal0, attr.normal1, attr.normal2};
+        float* tan[3] = {attr.tangent0, attr.tangent1, attr.tangent2};
+        float* uvs[3] = {attr.uv0, attr.uv1, attr.uv2};
+        for (int k = 0; k < 3; k++) {
+            uint32_t base = vertIndices[k] * M->VertexStride;
+            f3 vert = VertexBuffer.LoadFloat3(base + M->PositionOffset);
+            vert = xyz(mulMV(M->LocalToWorld, f4{vert.x, vert.y, vert.z, 1.0f}));
+            float* vp = vertexPositionBuffer + 4 * (size_t)(writeIndex + k);
+            vp[0] = vert.x; vp[1] = vert.y; vp[2] = vert.z; vp[3] = 0.0f;
+            if (M->flags & PT_MESH_HAS_NORMALS) {
+                f3 n = VertexBuffer.LoadFloat3(base + M->NormalOffset);
+                n = normalize(xyz(mulVM(f4{n.x, n.y, n.z, 0.0f}, M->WorldToLocal)));
+                nrm[k][0] = n.x; nrm[k][1] = n.y; nrm[k][2] = n.z;
+            }
+            if (M->flags & PT_MESH_HAS_TANGENTS) {
+                f3 t = VertexBuffer.LoadFloat3(base + M->TangentOffset);
+                t = normalize(xyz(mulMV(M->LocalToWorld, f4{t.x, t.y, t.z, 0.0f})));
+                tan[k][0] = t.x; tan[k][1] = t.y; tan[k][2] = t.z;
+            }
+            if (M->flags & PT_MESH_HAS_UVS) {
+                uvs[k][0] = pt_asfloat(VertexBuffer.Load(base + M->UVOffset));
+                uvs[k][1] = pt_asfloat(VertexBuffer.Load(base + M->UVOffset + 4));
+            }
+        }
+        attr.materialIndex = M->MaterialIndex;
+        out[writeTriIndex] = attr;
+    }
+    return 0;
+}
+
+int oracle_copy_texture_data(const PTTextureDesc* textures, uint32_t count, uint32_t* TextureData)
+{
+    if (!textures || !TextureData) return -1;
+    int textureDescriptorOffset = 0;
+    int textureDataOffset = (int)count * 4;                                           // BVHScene.cs:388-389
+    for (uint32_t t = 0; t < count; t++) {
+        const uint32_t TextureWidth = textures[t].width, TextureHeight = textures[t].height;
+        for (uint32_t pixelY = 0; pixelY < TextureHeight; pixelY++)
+            for (uint32_t pixelX = 0; pixelX < TextureWidth; pixelX++) {              // CopyTextureData.compute:13-36
+                uint32_t pixelIndex = pixelY * TextureWidth + pixelX;
+                TextureData[textureDescriptorOffset + 0] = TextureWidth;
+                TextureData[textureDescriptorOffset + 1] = TextureHeight;
+                TextureData[textureDescriptorOffset + 2] = (uint32_t)textureDataOffset;
+                TextureData[textureDescriptorOffset + 3] = 0;
+                const float* texel = textures[t].texels + 4 * (size_t)pixelIndex;
+                uint32_t r = pt_f2u(texel[0] * 255.0f) & 0xff;
+                uint32_t g = pt_f2u(texel[1] * 255.0f) & 0xff;
+                uint32_t b = pt_f2u(texel[2] * 255.0f) & 0xff;
+                uint32_t a = textures[t].hasAlpha ? pt_f2u(texel[3] * 255.0f) & 0xff : 0xff;
+                TextureData[pixelIndex + (uint32_t)textureDataOffset] = (a << 24) | (b << 16) | (g << 8) | r;
+            }
+        textureDataOffset += (int)(TextureWidth * TextureHeight);                      // :413-414
+        textureDescriptorOffset += 4;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // util/tonemap.hlsl + Presentation.shader FragBlit
 // ------------------------------------------------------------------------------------------
 namespace {

@@ -75,6 +75,11 @@ void     oracle_sample_brdf(const float* material, const float* V, const float* 
  * Returns EnvironmentCdfSum. */
 float    oracle_env_probe(const PTSceneDesc* scene, const PTFrameParams* params, int what, const float* in, uint64_t n, float* out);
 
+/* Scene ingestion: one Dispatch of MeshProcessing.compute:59-139 (writes triangles [OutputTriangleStart, +TriangleCount) of both
+ * output buffers) and the texture loop of BVHScene.cs:386-417 over CopyTextureData.compute:13-36. */
+int      oracle_process_mesh(const PTMeshDesc* mesh, float* vertexPositionBuffer, void* triangleAttributesBuffer);
+int      oracle_copy_texture_data(const PTTextureDesc* textures, uint32_t count, uint32_t* textureData);
+
 /* The presentation blit, Assets/Resources/Presentation.shader:36-73 + util/tonemap.hlsl, one pixel after the other. */
 int      oracle_present(const PTPresentParams* params, const float* srcRGBA, float* dstRGBA);
 

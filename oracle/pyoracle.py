@@ -70,6 +70,10 @@ def load_oracle():
         lib.oracle_eval_brdf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
         lib.oracle_sample_brdf.restype = None
         lib.oracle_sample_brdf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]
+        lib.oracle_process_mesh.restype = C.c_int
+        lib.oracle_process_mesh.argtypes = [C.POINTER(abi.PTMeshDesc), C.c_void_p, C.c_void_p]
+        lib.oracle_copy_texture_data.restype = C.c_int
+        lib.oracle_copy_texture_data.argtypes = [C.POINTER(abi.PTTextureDesc), C.c_uint32, C.c_void_p]
         lib.oracle_present.restype = C.c_int
         lib.oracle_present.argtypes = [C.POINTER(abi.PTPresentParams), C.c_void_p, C.c_void_p]
         lib.oracle_env_probe.restype = C.c_float
@@ -276,3 +280,29 @@ def present(params, frame: np.ndarray) -> np.ndarray:
     rc = load_oracle().oracle_present(C.byref(params), src.ctypes.data, dst.ctypes.data)
     assert rc == 0
     return dst
+
+
+def process_meshes(descs, total_triangles: int):
+    """oracle_process_mesh over a list of abi.PTMeshDesc -> (vertex positions (T*3, 4) f32, attributes (T,) TRI_ATTR)."""
+    lib = load_oracle()
+    pos = np.zeros((total_triangles * 3, 4), dtype=np.float32)
+    attrs = np.zeros(total_triangles, dtype=abi.TRI_ATTR)
+    for d in descs:
+        assert lib.oracle_process_mesh(C.byref(d), pos.ctypes.data, attrs.ctypes.data) == 0
+    return pos, attrs
+
+
+def copy_texture_data(images):
+    """oracle_copy_texture_data over [(h, w, 4) float32 image, has_alpha] pairs -> TextureData uint32."""
+    lib = load_oracle()
+    arr = (abi.PTTextureDesc * len(images))()
+    keep = []
+    total = 4 * len(images)
+    for i, (img, has_alpha) in enumerate(images):
+        a = np.ascontiguousarray(img, dtype=np.float32)
+        keep.append(a)
+        arr[i].texels, arr[i].height, arr[i].width, arr[i].hasAlpha = a.ctypes.data, a.shape[0], a.shape[1], 1 if has_alpha else 0
+        total += a.shape[0] * a.shape[1]
+    out = np.zeros(total, dtype=np.uint32)
+    assert lib.oracle_copy_texture_data(arr, len(images), out.ctypes.data) == 0
+    return out

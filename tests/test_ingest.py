@@ -1,0 +1,229 @@
+"""Scene ingestion: MeshProcessing.compute / CopyTextureData.compute restated in the oracle, checked against
+independent numpy formulations and the existing packers, and (gpu) the HIP kernels against the oracle, bit for bit."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from unity_webgpu_pathtracer_amd import abi, ingest, plugin, scenes
+
+
+def _trs():
+    a, b = 0.7, -0.4
+    ry = np.array([[np.cos(a), 0, np.sin(a), 0], [0, 1, 0, 0], [-np.sin(a), 0, np.cos(a), 0], [0, 0, 0, 1]])
+    rx = np.array([[1, 0, 0, 0], [0, np.cos(b), -np.sin(b), 0], [0, np.sin(b), np.cos(b), 0], [0, 0, 0, 1]])
+    sc = np.diag([1.5, 0.5, 2.0, 1.0])
+    t = np.eye(4)
+    t[:3, 3] = [3.0, -1.0, 0.25]
+    return t @ ry @ rx @ sc
+
+
+def _random_mesh(rng, nverts, ntris, indexed, dtype, normals=True, tangents=True, uvs=True, l2w=None, mat=0):
+    pos = rng.normal(0, 1, (nverts, 3)).astype(np.float32)
+    nrm = rng.normal(0, 1, (nverts, 3)).astype(np.float32) if normals else None
+    tan = rng.normal(0, 1, (nverts, 3)).astype(np.float32) if tangents else None
+    uv = rng.uniform(-2, 2, (nverts, 2)).astype(np.float32) if uvs else None
+    idx = rng.randint(0, nverts, ntris * 3).astype(dtype) if indexed else None
+    if not indexed:
+        pos, nrm, tan, uv = [None if a is None else a[: (nverts // 3) * 3] for a in (pos, nrm, tan, uv)]
+    return ingest.Mesh(pos, nrm, tan, uv, idx, np.eye(4) if l2w is None else l2w, mat)
+
+
+def _numpy_process(m: ingest.Mesh):
+    idx = m.indices.astype(np.int64) if m.indices is not None else np.arange(len(m.positions))
+    L = np.asarray(m.local_to_world, np.float64)
+    W = np.linalg.inv(L)
+    p = m.positions[idx].astype(np.float64) @ L[:3, :3].T + L[:3, 3]
+    out = {"pos": p}
+    if m.normals is not None:
+        n = m.normals[idx].astype(np.float64) @ W[:3, :3]                  # row vector times worldToLocal = inverse transpose
+        out["n"] = n / np.linalg.norm(n, axis=1, keepdims=True)
+    if m.tangents is not None:
+        t = m.tangents[idx].astype(np.float64) @ L[:3, :3].T
+        out["t"] = t / np.linalg.norm(t, axis=1, keepdims=True)
+    if m.uvs is not None:
+        out["uv"] = m.uvs[idx].astype(np.float64)
+    return out
+
+
+def _check_against_numpy(m, pos, attrs, start):
+    ref = _numpy_process(m)
+    T = m.triangle_count
+    sl = slice(start * 3, (start + T) * 3)
+    assert np.abs(pos[sl, :3] - ref["pos"]).max() < 2e-5 and (pos[sl, 3] == 0).all()
+    a = attrs[start:start + T]
+    if "n" in ref:
+        got = np.stack([a["normal0"], a["normal1"], a["normal2"]], 1).reshape(-1, 3)
+        assert np.abs(got - ref["n"]).max() < 2e-6
+    else:
+        assert not a["normal0"].any()
+    if "t" in ref:
+        got = np.stack([a["tangent0"], a["tangent1"], a["tangent2"]], 1).reshape(-1, 3)
+        assert np.abs(got - ref["t"]).max() < 2e-6
+    if "uv" in ref:
+        got = np.stack([a["uv0"], a["uv1"], a["uv2"]], 1).reshape(-1, 2)
+        assert np.array_equal(got, ref["uv"].astype(np.float32))
+    assert (a["materialIndex"] == m.material_index).all()
+
+
+def _mesh_zoo():
+    rng = np.random.RandomState(8)
+    L = _trs()
+    return [
+        _random_mesh(rng, 50, 33, True, np.uint16, l2w=L, mat=3),                        # odd triangle count: both 16-bit alignments
+        _random_mesh(rng, 70000, 40, True, np.uint32, l2w=L, mat=1),
+        _random_mesh(rng, 30, 10, False, None, l2w=L, mat=2),                            # no index buffer
+        _random_mesh(rng, 20, 7, True, np.uint16, normals=False, tangents=False, uvs=False, mat=0),
+        _random_mesh(rng, 20, 9, True, np.uint16, tangents=False, l2w=np.diag([2.0, 2.0, 2.0, 1.0]), mat=5),
+    ]
+
+
+def test_oracle_process_mesh_matches_numpy(oracle):
+    meshes = _mesh_zoo()
+    descs, total, keep = ingest.mesh_descs(meshes)
+    pos, attrs = oracle.process_meshes(list(descs), total)
+    start = 0
+    for m in meshes:
+        _check_against_numpy(m, pos, attrs, start)
+        start += m.triangle_count
+    assert start == total
+
+
+def test_oracle_copy_texture_data_matches_packer(oracle):
+    imgs = [scenes.tex_checker(16, (0.9, 0.9, 0.9, 1), (0.2, 0.2, 0.25, 0.5), 4), scenes.tex_noise(8, (0, 0.9, 0, 1), (0, 0.2, 1, 1), seed=3)]
+    imgs.append(np.random.RandomState(1).uniform(0, 1, (5, 11, 4)).astype(np.float32))      # not a multiple of the 8x8 group
+    got = oracle.copy_texture_data([(i, True) for i in imgs])
+    assert np.array_equal(got, scenes.pack_textures(imgs))                                  # the packer the synthetic scenes use
+    noalpha = oracle.copy_texture_data([(imgs[2], False)])
+    assert ((noalpha[4:] >> 24) == 0xFF).all() and np.array_equal(noalpha[:4], [11, 5, 4, 0])
+    odd = np.array([[[1.5, -0.2, np.nan, 0.999]]], dtype=np.float32)                         # (uint)(x * 255) & 0xff on out-of-range texels
+    w = int(oracle.copy_texture_data([(odd, True)])[4])
+    assert w == ((254 << 24) | (0 << 16) | (0 << 8) | (382 & 0xFF))
+
+
+CUBE_OBJ = """# unit cube, quads, shared normals per face, negative indices on the last face
+o cube
+v -1 -1 -1
+v 1 -1 -1
+v 1 1 -1
+v -1 1 -1
+v -1 -1 1
+v 1 -1 1
+v 1 1 1
+v -1 1 1
+vt 0 0
+vt 1 0
+vt 1 1
+vt 0 1
+vn 0 0 -1
+vn 0 0 1
+vn -1 0 0
+vn 1 0 0
+vn 0 -1 0
+vn 0 1 0
+usemtl red
+f 1/1/1 4/4/1 3/3/1 2/2/1
+f 5/1/2 6/2/2 7/3/2 8/4/2
+usemtl green
+f 1/1/3 5/2/3 8/3/3 4/4/3
+f 2/1/4 3/4/4 7/3/4 6/2/4
+f 1/1/5 2/2/5 6/3/5 5/4/5
+f -5/1/-1 -1/2/-1 -2/3/-1 -6/4/-1
+"""
+
+
+def test_obj_loader(tmp_path, oracle):
+    path = tmp_path / "cube.obj"
+    path.write_text(CUBE_OBJ)
+    meshes, names = ingest.load_obj(str(path))
+    assert names == ["red", "green"] and [m.triangle_count for m in meshes] == [4, 8]
+    assert meshes[0].indices.dtype == np.uint16 and meshes[0].normals is not None and meshes[0].uvs is not None
+    descs, total, keep = ingest.mesh_descs(meshes)
+    pos, attrs = oracle.process_meshes(list(descs), total)
+    assert total == 12 and np.array_equal(pos[:, :3].min(0), [-1, -1, -1]) and np.array_equal(pos[:, :3].max(0), [1, 1, 1])
+    assert (attrs["materialIndex"][:4] == 0).all() and (attrs["materialIndex"][4:] == 1).all()
+    # the negative-index face is the +y face (vertices 4, 8, 7, 3): its normal is (0, 1, 0)
+    assert np.array_equal(attrs["normal0"][-1], [0, 1, 0]) and np.allclose(pos[-3:, 1], 1.0)
+    # every face normal agrees with the geometric normal up to sign
+    tri = pos[:, :3].reshape(-1, 3, 3)
+    g = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    assert np.allclose(np.abs((g * attrs["normal0"]).sum(1)), 1.0)
+
+
+def test_ingest_rejects_bad_input_without_touching_the_gpu():
+    lib = plugin.load_library()
+    assert lib.PTProcessMeshes(None, None, 0, 0, None, None) == abi.PT_ERR_INVALID_ARG
+    assert lib.PTCopyTextureData(None, None, 0, None, 0) == abi.PT_ERR_INVALID_ARG
+
+
+# ---------------------------------------------------------------------------------------
+# GPU: the HIP kernels against the oracle
+# ---------------------------------------------------------------------------------------
+@pytest.fixture()
+def ctx():
+    lib = plugin.load_library()
+    c = C.c_void_p()
+    plugin.check(lib.PTCreate(0, C.byref(c)))
+    yield c
+    lib.PTDestroy(c)
+
+
+@pytest.mark.gpu
+def test_gpu_process_meshes_bit_exact(oracle, ctx):
+    meshes = _mesh_zoo()
+    pos, attrs = ingest.process_meshes(ctx, meshes)
+    descs, total, keep = ingest.mesh_descs(meshes)
+    rpos, rattrs = oracle.process_meshes(list(descs), total)
+    assert np.array_equal(pos.view(np.uint32), rpos.view(np.uint32))
+    assert np.array_equal(attrs.view(np.uint8), rattrs.view(np.uint8))
+
+
+@pytest.mark.gpu
+def test_gpu_process_meshes_validates_buffers(ctx):
+    lib = plugin.load_library()
+    m = _random_mesh(np.random.RandomState(2), 10, 4, True, np.uint16)
+    m.indices[5] = 200                                                # points past the vertex buffer
+    arr, total, keep = ingest.mesh_descs([m])
+    pos = np.zeros((total * 3, 4), np.float32)
+    attrs = np.zeros(total, abi.TRI_ATTR)
+    rc = lib.PTProcessMeshes(ctx, arr, 1, total, pos.ctypes.data_as(C.c_void_p), attrs.ctypes.data_as(C.c_void_p))
+    assert rc == abi.PT_ERR_INVALID_ARG and b"vertex buffer too small" in lib.PTGetLastError()
+
+
+@pytest.mark.gpu
+def test_gpu_copy_texture_data_bit_exact(oracle, ctx):
+    rng = np.random.RandomState(3)
+    imgs = [(rng.uniform(-0.2, 1.3, (h, w, 4)).astype(np.float32), alpha) for (h, w, alpha) in ((8, 8, True), (5, 11, False), (33, 17, True), (1, 1, True))]
+    imgs[2][0][0, 0] = np.nan
+    got = ingest.copy_texture_data(ctx, imgs)
+    assert np.array_equal(got, oracle.copy_texture_data(imgs))
+
+
+@pytest.mark.gpu
+def test_gpu_obj_to_frame(tmp_path, oracle, ctx):
+    """OBJ file -> ingestion kernels -> BuildBVH -> render: the frame equals the oracle's frame of the same buffers."""
+    from unity_webgpu_pathtracer_amd.pathtracer import PathTracer
+    path = tmp_path / "cube.obj"
+    path.write_text(CUBE_OBJ)
+    meshes, names = ingest.load_obj(str(path))
+    meshes[0].local_to_world = _trs() @ np.diag([0.4, 0.4, 0.4, 1.0])
+    meshes[1].local_to_world = meshes[0].local_to_world
+    floor = ingest.Mesh(np.array([[-6, -1.5, -6], [6, -1.5, -6], [6, -1.5, 6], [-6, -1.5, 6]], np.float32),
+                        np.tile(np.array([[0, 1, 0]], np.float32), (4, 1)), None, np.array([[0, 0], [4, 0], [4, 4], [0, 4]], np.float32),
+                        np.array([0, 2, 1, 0, 3, 2], np.uint16), np.eye(4), 2)
+    tex = [(scenes.tex_checker(16, (0.9, 0.9, 0.9, 1), (0.1, 0.1, 0.1, 1), 4), True)]
+    mats = np.stack([scenes.pack_material(color=(0.8, 0.1, 0.1, 1), roughness=0.4), scenes.pack_material(color=(0.1, 0.7, 0.2, 1), roughness=0.2, metallic=1.0),
+                     scenes.pack_material(color=(1, 1, 1, 1), roughness=0.9, tex_base=0)])
+    cam = scenes.Camera(eye=(0.5, 2.5, -7.0), target=(3.0, -0.8, 0.25), vfov_deg=40.0)
+    s = ingest.scene_from_meshes(ctx, meshes + [floor], mats, cam, images=tex, environment_mode=1, environment_intensity=1.0)
+    assert s.tri_count == 14 and s.texture_data.size == 4 + 256
+    pt = PathTracer(s, width=96, height=64, samplesPerPass=3)
+    p = pt.params(seed=0xB0B)
+    pt.render_pass(p)
+    gpu = pt.readback()
+    ref, _ = oracle.render(oracle.buffers_from_bvhscene(pt._bvhScene), p)
+    assert np.array_equal(gpu.view(np.uint32), ref.view(np.uint32))
+    assert gpu[..., :3].std() > 0.05                                  # an actual picture, not a constant
+    pt.close()

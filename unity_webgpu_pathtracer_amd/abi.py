@@ -140,6 +140,24 @@ class PTPresentParams(C.Structure):
 TONEMAP_NONE, TONEMAP_ACES, TONEMAP_FILMIC, TONEMAP_REINHARD, TONEMAP_LOTTES = range(5)      # PathTracer.cs:8-14
 
 
+PT_MESH_HAS_32_BIT_INDICES, PT_MESH_HAS_NORMALS, PT_MESH_HAS_TANGENTS, PT_MESH_HAS_UVS = 0x1, 0x2, 0x4, 0x8
+
+
+class PTMeshDesc(C.Structure):
+    """One Dispatch of MeshProcessing.compute (BVHScene.cs:489-553)."""
+    _fields_ = [("vertexBuffer", C.c_void_p), ("vertexBufferBytes", C.c_uint64),
+                ("indexBuffer", C.c_void_p), ("indexBufferBytes", C.c_uint64),
+                ("VertexStride", C.c_uint32), ("PositionOffset", C.c_uint32), ("NormalOffset", C.c_uint32),
+                ("TangentOffset", C.c_uint32), ("UVOffset", C.c_uint32), ("MaterialIndex", C.c_uint32),
+                ("TriangleCount", C.c_uint32), ("OutputTriangleStart", C.c_uint32),
+                ("LocalToWorld", C.c_float * 16), ("WorldToLocal", C.c_float * 16),
+                ("flags", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+class PTTextureDesc(C.Structure):
+    _fields_ = [("texels", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("hasAlpha", C.c_int32), ("_pad", C.c_uint32)]
+
+
 class PTTimings(C.Structure):
     _fields_ = [("passes", C.c_uint64), ("kernelMsTotal", C.c_double),
                 ("kernelMsLast", C.c_double), ("kernelLaunches", C.c_uint64)]

@@ -403,6 +403,101 @@ PT_API int PTReadback(PTContext* c, float* dst, uint64_t dstFloats)
     return PT_OK;
 }
 
+namespace {
+struct ScopedDev {                      // device scratch that is freed on every exit path
+    void* p = nullptr;
+    ~ScopedDev() { if (p) hipFree(p); }
+};
+}
+
+PT_API int PTProcessMeshes(PTContext* c, const PTMeshDesc* meshes, uint32_t meshCount, uint32_t totalTriangles,
+                           float* outVertexPositions, void* outTriangleAttributes)
+{
+    if (!c || !meshes || meshCount == 0 || totalTriangles == 0 || !outVertexPositions || !outTriangleAttributes)
+        return fail(PT_ERR_INVALID_ARG, "ctx/meshes/outputs == NULL or nothing to process");
+    for (uint32_t i = 0; i < meshCount; ++i) {
+        const PTMeshDesc& m = meshes[i];
+        if (!m.vertexBuffer || m.VertexStride == 0) return fail(PT_ERR_INVALID_ARG, "mesh without vertex buffer / stride");
+        if ((m.VertexStride | m.PositionOffset | m.NormalOffset | m.TangentOffset | m.UVOffset) & 3u)
+            return fail(PT_ERR_INVALID_ARG, "vertex stride and attribute offsets must be multiples of 4 (ByteAddressBuffer loads)");
+        if ((uint64_t)m.OutputTriangleStart + m.TriangleCount > totalTriangles) return fail(PT_ERR_INVALID_ARG, "mesh writes past totalTriangles");
+        // every index the kernel will read must stay inside the buffers the caller handed over
+        uint64_t maxIndex;
+        if (m.indexBuffer) {
+            const bool wide = (m.flags & PT_MESH_HAS_32_BIT_INDICES) != 0;
+            const uint64_t need = (uint64_t)m.TriangleCount * (wide ? 12u : 6u);
+            if (m.indexBufferBytes < need) return fail(PT_ERR_INVALID_ARG, "index buffer too small for TriangleCount");
+            maxIndex = 0;
+            for (uint64_t k = 0; k < (uint64_t)m.TriangleCount * 3u; ++k) {
+                const uint64_t v = wide ? ((const uint32_t*)m.indexBuffer)[k] : ((const uint16_t*)m.indexBuffer)[k];
+                if (v > maxIndex) maxIndex = v;
+            }
+        } else maxIndex = m.TriangleCount ? (uint64_t)m.TriangleCount * 3u - 1u : 0u;
+        uint32_t far = m.PositionOffset + 12u;
+        if ((m.flags & PT_MESH_HAS_NORMALS) && m.NormalOffset + 12u > far) far = m.NormalOffset + 12u;
+        if ((m.flags & PT_MESH_HAS_TANGENTS) && m.TangentOffset + 12u > far) far = m.TangentOffset + 12u;
+        if ((m.flags & PT_MESH_HAS_UVS) && m.UVOffset + 8u > far) far = m.UVOffset + 8u;
+        if (m.TriangleCount && maxIndex * m.VertexStride + far > m.vertexBufferBytes) return fail(PT_ERR_INVALID_ARG, "vertex buffer too small for the indices used");
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    ScopedDev dPos, dAttr;
+    const size_t posBytes = (size_t)totalTriangles * 3 * sizeof(float4), attrBytes = (size_t)totalTriangles * 128;
+    HIP_TRY(hipMalloc(&dPos.p, posBytes));
+    HIP_TRY(hipMalloc(&dAttr.p, attrBytes));
+    HIP_TRY(hipMemsetAsync(dPos.p, 0, posBytes, c->stream));
+    HIP_TRY(hipMemsetAsync(dAttr.p, 0, attrBytes, c->stream));
+    for (uint32_t i = 0; i < meshCount; ++i) {
+        const PTMeshDesc& m = meshes[i];
+        if (m.TriangleCount == 0) continue;
+        ScopedDev dVb, dIb;
+        // the 16-bit path reads two whole words around the last index: pad the staged copy
+        const size_t ibBytes = m.indexBuffer ? (((size_t)m.indexBufferBytes + 3u) & ~(size_t)3u) + 8u : 0u;
+        HIP_TRY(hipMalloc(&dVb.p, m.vertexBufferBytes));
+        HIP_TRY(hipMemcpyAsync(dVb.p, m.vertexBuffer, m.vertexBufferBytes, hipMemcpyHostToDevice, c->stream));
+        if (m.indexBuffer) {
+            HIP_TRY(hipMalloc(&dIb.p, ibBytes));
+            HIP_TRY(hipMemsetAsync(dIb.p, 0, ibBytes, c->stream));
+            HIP_TRY(hipMemcpyAsync(dIb.p, m.indexBuffer, m.indexBufferBytes, hipMemcpyHostToDevice, c->stream));
+        }
+        HIP_TRY(pt_launch_process_mesh(m, dVb.p, dIb.p, (float4*)dPos.p, (float4*)dAttr.p, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));      // the staged buffers go out of scope
+    }
+    HIP_TRY(hipMemcpyAsync(outVertexPositions, dPos.p, posBytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(outTriangleAttributes, dAttr.p, attrBytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+PT_API int PTCopyTextureData(PTContext* c, const PTTextureDesc* textures, uint32_t count, uint32_t* outTextureData, uint64_t outUints)
+{
+    if (!c || !textures || count == 0 || !outTextureData) return fail(PT_ERR_INVALID_ARG, "ctx/textures/output == NULL");
+    uint64_t total = (uint64_t)count * 4u;
+    for (uint32_t i = 0; i < count; ++i) {
+        if (!textures[i].texels || textures[i].width == 0 || textures[i].height == 0) return fail(PT_ERR_INVALID_ARG, "empty texture");
+        total += (uint64_t)textures[i].width * textures[i].height;
+    }
+    if (total > 0xFFFFFFFFull) return fail(PT_ERR_INVALID_ARG, "texture data exceeds the 32-bit offsets of the descriptor");
+    if (outUints < total) return fail(PT_ERR_INVALID_ARG, "outTextureData too small");
+    HIP_TRY(hipSetDevice(c->device));
+    ScopedDev dData;
+    HIP_TRY(hipMalloc(&dData.p, total * 4u));
+    uint32_t descriptorOffset = 0u, dataOffset = count * 4u;            // texel data starts after the descriptors (BVHScene.cs:388-389)
+    for (uint32_t i = 0; i < count; ++i) {
+        const PTTextureDesc& t = textures[i];
+        const size_t bytes = (size_t)t.width * t.height * sizeof(float4);
+        ScopedDev dTex;
+        HIP_TRY(hipMalloc(&dTex.p, bytes));
+        HIP_TRY(hipMemcpyAsync(dTex.p, t.texels, bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(pt_launch_copy_texture((const float4*)dTex.p, t.width, t.height, dataOffset, descriptorOffset, t.hasAlpha, (uint32_t*)dData.p, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        dataOffset += t.width * t.height;
+        descriptorOffset += 4u;
+    }
+    HIP_TRY(hipMemcpyAsync(outTextureData, dData.p, total * 4u, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
 PT_API int PTPresent(PTContext* c, const PTPresentParams* q, const void* dSrc, void* dDst)
 {
     if (!c || !q || !dDst) return fail(PT_ERR_INVALID_ARG, "ctx/params/dst == NULL");

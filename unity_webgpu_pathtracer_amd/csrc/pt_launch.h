@@ -14,6 +14,10 @@ struct PTTileMap {
 hipError_t pt_launch_megakernel(const DScene& S, const PTFrameParams& P, const float4* accumulated, float4* output,
                                 const PTTileMap& tm, unsigned long long* gstats, bool fullStats, hipStream_t stream);
 
+hipError_t pt_launch_process_mesh(const PTMeshDesc& M, const void* dVertexBuffer, const void* dIndexBuffer, float4* dVertexPositions,
+                                  float4* dTriangleAttributes, hipStream_t stream);
+hipError_t pt_launch_copy_texture(const float4* dTexture, uint32_t width, uint32_t height, uint32_t dataOffset, uint32_t descriptorOffset,
+                                  int hasAlpha, uint32_t* dTextureData, hipStream_t stream);
 hipError_t pt_launch_present(const PTPresentParams& Q, const float4* src, float4* dst, hipStream_t stream);
 
 // ---- schedule 1 (wavefront): slot-indexed path state in HBM (see pt_wavefront.hip) ----

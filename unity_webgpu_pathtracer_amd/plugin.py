@@ -63,6 +63,8 @@ def load_library():
         "PTGetFramePointer": (vp, [vp, i32]), "PTGetStream": (vp, [vp]),
         "PTSetStatsLevel": (i32, [vp, i32]), "PTGetStats": (i32, [vp, C.POINTER(abi.PTStats)]), "PTResetStats": (i32, [vp]),
         "PTSetProfiling": (i32, [vp, i32]), "PTGetTimings": (i32, [vp, C.POINTER(abi.PTTimings)]), "PTResetTimings": (i32, [vp]),
+        "PTProcessMeshes": (i32, [vp, C.POINTER(abi.PTMeshDesc), C.c_uint32, C.c_uint32, vp, vp]),
+        "PTCopyTextureData": (i32, [vp, C.POINTER(abi.PTTextureDesc), C.c_uint32, vp, C.c_uint64]),
         "PTPresent": (i32, [vp, C.POINTER(abi.PTPresentParams), vp, vp]),
         "PTPresentToHost": (i32, [vp, C.POINTER(abi.PTPresentParams), vp, C.c_uint64]),
         "PTSetSchedule": (i32, [vp, i32]), "PTGetSchedule": (i32, [vp]), "PTSetWavefrontIterations": (i32, [vp, i32]),
@@ -81,7 +83,7 @@ EXPORTED_SYMBOLS = [
     "BuildTLAS", "DestroyTLAS", "IsTLASReady", "GetTLASNodesSize", "GetTLASData",
     "PTCreate", "PTDestroy", "PTSetScene", "PTSetTileOwnership", "PTRenderPass", "PTFlipFrames", "PTResetFrames",
     "PTRenderPassTo", "PTSynchronize", "PTReadback", "PTGetFramePointer", "PTGetStream", "PTSetStatsLevel", "PTGetStats",
-    "PTResetStats", "PTSetProfiling", "PTGetTimings", "PTResetTimings", "PTPresent", "PTPresentToHost", "PTSetSchedule", "PTGetSchedule", "PTSetWavefrontIterations",
+    "PTResetStats", "PTSetProfiling", "PTGetTimings", "PTResetTimings", "PTProcessMeshes", "PTCopyTextureData", "PTPresent", "PTPresentToHost", "PTSetSchedule", "PTGetSchedule", "PTSetWavefrontIterations",
     "PTGetLastError", "PTGetVersion",
 ]
 
