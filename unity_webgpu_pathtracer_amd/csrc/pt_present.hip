@@ -47,20 +47,26 @@ PT_DEV v3 tm_filmic(v3 x)
     return pow3(result, 2.2f);
 }
 
-// :57-74
-PT_DEV v3 tm_lottes(v3 x)
+// :57-74.  b and c depend on constants only: the launcher evaluates them once on the host with the same canonical pt_pow
+// (bit-identical to evaluating them per pixel) instead of five pow() per pixel here.
+struct LottesConsts { float a, ad, b, c; };
+PT_HD LottesConsts lottes_consts()
 {
     const float a = 1.6f, d = 0.977f, hdrMax = 8.0f, midIn = 0.18f, midOut = 0.267f;
-    const float b = (-pt_pow(midIn, a) + pt_pow(hdrMax, a) * midOut) / ((pt_pow(hdrMax, a * d) - pt_pow(midIn, a * d)) * midOut);
-    const float c = (pt_pow(hdrMax, a * d) * pt_pow(midIn, a) - pt_pow(hdrMax, a) * pt_pow(midIn, a * d) * midOut) /
-                    ((pt_pow(hdrMax, a * d) - pt_pow(midIn, a * d)) * midOut);
-    return div33(pow3(x, a), pow3(x, a * d) * b + mk3(c));
+    LottesConsts k;
+    k.a = a;
+    k.ad = a * d;
+    k.b = (-pt_pow(midIn, a) + pt_pow(hdrMax, a) * midOut) / ((pt_pow(hdrMax, a * d) - pt_pow(midIn, a * d)) * midOut);
+    k.c = (pt_pow(hdrMax, a * d) * pt_pow(midIn, a) - pt_pow(hdrMax, a) * pt_pow(midIn, a * d) * midOut) /
+          ((pt_pow(hdrMax, a * d) - pt_pow(midIn, a * d)) * midOut);
+    return k;
 }
+PT_DEV v3 tm_lottes(v3 x, const LottesConsts& k) { return div33(pow3(x, k.a), pow3(x, k.ad) * k.b + mk3(k.c)); }
 
 // :76-79
 PT_DEV v3 tm_reinhard(v3 x) { return div33(x, mk3(1.0f) + x); }
 
-__global__ __launch_bounds__(256) void pt_present(PTPresentParams Q, const float4* __restrict__ src, float4* __restrict__ dst)
+__global__ __launch_bounds__(256) void pt_present(PTPresentParams Q, LottesConsts LK, const float4* __restrict__ src, float4* __restrict__ dst)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     const uint32_t n = Q.OutputWidth * Q.OutputHeight;
@@ -73,7 +79,7 @@ __global__ __launch_bounds__(256) void pt_present(PTPresentParams Q, const float
     case 1: color = tm_aces(color); break;
     case 2: color = tm_filmic(color); break;
     case 3: color = tm_reinhard(color); break;
-    case 4: color = tm_lottes(color); break;
+    case 4: color = tm_lottes(color, LK); break;
     default: break;
     }
     if (Q.sRGB) color = linear_to_srgb(color);
@@ -95,6 +101,6 @@ __global__ __launch_bounds__(256) void pt_present(PTPresentParams Q, const float
 hipError_t pt_launch_present(const PTPresentParams& Q, const float4* src, float4* dst, hipStream_t stream)
 {
     const uint32_t n = Q.OutputWidth * Q.OutputHeight;
-    hipLaunchKernelGGL(pt_present, dim3((n + 255u) / 256u), dim3(256), 0, stream, Q, src, dst);
+    hipLaunchKernelGGL(pt_present, dim3((n + 255u) / 256u), dim3(256), 0, stream, Q, lottes_consts(), src, dst);
     return hipGetLastError();
 }
