@@ -291,3 +291,76 @@ def test_tlas_progressive_and_cleanup(oracle):
     _, nbad = _compare(gpu, ref, "instanced, 3 pipelined passes, cleanup kernel")
     assert nbad == 0
     pt.close()
+
+
+@pytest.mark.parametrize("schedule", SCHEDULES)
+@pytest.mark.parametrize("w,h,spp,bounces", [(1, 1, 3, 4), (7, 5, 2, 1), (17, 33, 1, 9), (257, 3, 2, 4)])
+def test_ragged_frame_sizes_and_depths(oracle, w, h, spp, bounces, schedule):
+    """Frames far from the 16x16 block / 8x8 tile grid, one-pixel frames, depth 1 and depth 9."""
+    s = scenes.material_zoo()
+    pt = PathTracer(s, width=w, height=h, samplesPerPass=spp, maxRayBounces=bounces, schedule=schedule)
+    pt.set_stats_level(1)
+    p = pt.params(seed=0x5EED + w)
+    pt.render_pass(p)
+    gpu = pt.readback()
+    ref, st = _oracle_frame(oracle, pt, p, shadow_any_hit=True)
+    _, nbad = _compare(gpu, ref, f"{w}x{h} spp {spp} depth {bounces}")
+    assert nbad == 0
+    _stats_equal(pt.stats(), st, ALL_COUNTERS)
+    pt.close()
+
+
+@pytest.mark.parametrize("world", [2, 5, 8])
+def test_tile_ownership_other_world_sizes(oracle, world):
+    """Every pixel is rendered by exactly one rank for world sizes that do and do not divide the block grid."""
+    s = scenes.cornell_box()
+    w, h, spp = 200, 120, 1
+    full = PathTracer(s, width=w, height=h, samplesPerPass=spp)
+    p = full.params(seed=4321)
+    full.render_pass(p)
+    f = full.readback()
+    full.close()
+    acc = np.zeros_like(f)
+    covered = np.zeros((h, w), dtype=np.int32)
+    for rank in range(world):
+        pt = PathTracer(s, width=w, height=h, samplesPerPass=spp, rank=rank, world_size=world)
+        pt.render_pass(p)
+        part = pt.readback()
+        covered += (part[..., 3] != 0).astype(np.int32)          # alpha is 1 on rendered pixels, 0 elsewhere
+        acc += part
+        pt.close()
+    assert (covered == 1).all()
+    assert np.array_equal(acc.view(np.uint32), f.view(np.uint32))
+
+
+def test_full_size_frame_windows_and_properties(oracle):
+    """BASELINE.json's headline configuration at FULL size (Sponza-class, 1920x1080, 8 spp, depth 4, two progressive passes):
+    windows of the frame against the oracle bit for bit, plus size-independent properties of the whole frame (determinism,
+    alpha, finiteness, per-pass ray budget)."""
+    s = scenes.sponza_atrium(tex_size=64)                          # full geometry (250,752 triangles); small textures keep the test light
+    W, H, SPP = 1920, 1080, 8
+    pt = PathTracer(s, width=W, height=H, samplesPerPass=SPP)
+    seeds = [0x12345678, (0x12345678 + 0x9E3779B9) & 0xFFFFFFFF]
+    p0 = pt.params(seeds[0])
+    pt.OnRenderImage(seeds[0])
+    f0 = pt.readback()
+    p1 = pt.params(seeds[1])
+    pt.OnRenderImage(seeds[1])
+    f1 = pt.readback()
+    st = pt.stats()
+    assert np.isfinite(f1).all() and (f1[..., 3] == 1.0).all() and (f1[..., :3] >= 0).all()
+    assert st.paths == 2 * W * H * SPP and st.pixelsWritten == 2 * W * H and st.pixelsRead == W * H
+    assert st.closestHitRays <= st.paths * 5 and st.shadowRays <= st.closestHitRays * 2        # <= 5 bounce rays, <= 2 NEE rays per hit
+    b = oracle.buffers_from_bvhscene(pt._bvhScene)
+    windows = [(0, 0, 24, 12), (948, 534, 972, 546), (1896, 1068, 1920, 1080), (300, 900, 324, 912), (1500, 200, 1524, 212), (700, 40, 724, 52)]
+    for (x0, y0, x1, y1) in windows:
+        r0, _ = oracle.render(b, p0, window=(x0, y0, x1, y1))
+        r1, _ = oracle.render(b, p1, accumulated=f0, window=(x0, y0, x1, y1))     # pass 2 reads pass 1 only at its own pixels
+        assert np.array_equal(f0[y0:y1, x0:x1].view(np.uint32), r0[y0:y1, x0:x1].view(np.uint32)), (x0, y0)
+        assert np.array_equal(f1[y0:y1, x0:x1].view(np.uint32), r1[y0:y1, x0:x1].view(np.uint32)), (x0, y0)
+    # determinism: the same two passes again give the same bits, whatever the scheduling of waves and passes was
+    pt.Reset()
+    pt.OnRenderImage(seeds[0])
+    pt.OnRenderImage(seeds[1])
+    assert np.array_equal(pt.readback().view(np.uint32), f1.view(np.uint32))
+    pt.close()

@@ -104,10 +104,13 @@ __global__ __launch_bounds__(256) void pt_wf_init(PTFrameParams P, PTTileMap tm,
     if (slot >= B.numSlots) return;
     uint32_t px, py;
     Counters cn = {};
-    if (!slot_to_pixel(tm, slot, px, py)) { B.flags[slot] = PS_DONE; return; }
-    PathRegs r;
-    path_init(P, px, py, py * P.OutputWidth + px, r, cn);
-    store_path(B, slot, r, false);
+    if (!slot_to_pixel(tm, slot, px, py)) B.flags[slot] = PS_DONE;
+    else {
+        PathRegs r;
+        path_init(P, px, py, py * P.OutputWidth + px, r, cn);
+        store_path(B, slot, r, false);
+    }
+    // every lane of the wave takes part in the reduction (a lane that had returned would be read as garbage)
     flush_counters<false>(cn, B.statRows, blockIdx.x * 4u + (threadIdx.x >> 6), threadIdx.x & 63u);
 }
 
