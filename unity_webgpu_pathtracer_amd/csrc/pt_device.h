@@ -1618,6 +1618,77 @@ PT_DEV bool ray_tri_phase(const DScene& S, RayState& r, Counters& cn)          /
     return false;
 }
 
+// Triangle phase for a whole wave: the pending (ray, triangle) pairs of all lanes are dealt out to the lanes, so a leaf with
+// three triangles occupies three lanes and a wave with five such rays runs ONE triangle block instead of three.  Up to three
+// triangles per ray and phase; the rest stays pending.  A worker lane fetches its pair's ray from the owner lane by
+// ds_bpermute, tests the triangle against the ray's current t, and the owner applies its results in the ray's own order
+// (accept iff dist < current t) -- the sequential loop of util/bvh.hlsl:179-190; an any-hit ray stops at, and counts up to,
+// its first accepted triangle.  Every lane of the wave must call this (the shuffles are wave-wide).
+template <bool STATS>
+PT_DEV bool wave_tri_gather(const DScene& S, RayState& r, bool want, volatile uint32_t* list, uint32_t lane, Counters& cn)
+{
+    const unsigned long long ltMask = (1ull << lane) - 1ull;
+    uint32_t bits = want ? r.tg.y : 0u;
+    uint32_t base = 0u, posPack = 0xFFFFFFFFu, taken = 0u;
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) {
+        const unsigned long long m = __ballot(bits != 0u);
+        if (m == 0ull || base >= 64u) break;
+        if (bits != 0u) {
+            const uint32_t idx = 31u - (uint32_t)__clz((int)bits);
+            const uint32_t pos = base + (uint32_t)__popcll(m & ltMask);
+            if (pos < 64u) {
+                list[pos] = lane | (idx << 8);
+                taken |= 1u << idx;
+                posPack = (posPack & ~(0xFFu << (8 * rr))) | (pos << (8 * rr));
+            }
+            bits &= ~(1u << idx);
+        }
+        base += (uint32_t)__popcll(m);
+    }
+    const uint32_t nPairs = base < 64u ? base : 64u;
+    __builtin_amdgcn_wave_barrier();
+    const bool worker = lane < nPairs;
+    const uint32_t e = worker ? list[lane] : lane;
+    const int src = (int)(e & 63u);
+    const uint32_t idx = e >> 8;
+    const v3 o = mk3(__shfl(r.o.x, src, 64), __shfl(r.o.y, src, 64), __shfl(r.o.z, src, 64));
+    const v3 d = mk3(__shfl(r.d.x, src, 64), __shfl(r.d.y, src, 64), __shfl(r.d.z, src, 64));
+    const float t0 = __shfl(r.hit.t, src, 64);
+    const uint32_t tgx = (uint32_t)__shfl((int)r.tg.x, src, 64);
+    TraceHit h;
+    h.t = PT_FAR_PLANE * 4.0f; h.u = 0.0f; h.v = 0.0f; h.triIndex = 0u;
+    if (worker) {
+        TraceHit w;
+        w.t = t0; w.u = 0.0f; w.v = 0.0f; w.triIndex = 0u;
+        intersect_triangle(S.tris, tgx + idx * 3u, o, d, w);
+        if (w.t < t0) h = w;                       // accepted against the pre-phase t; otherwise it can never be accepted
+    }
+    __builtin_amdgcn_wave_barrier();
+    // owners walk their results in order
+    bool accepted = false, stop = false;
+    int winner = (int)lane;
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) {
+        const uint32_t pos = (posPack >> (8 * rr)) & 255u;
+        const float rt = __shfl(h.t, pos == 255u ? (int)lane : (int)pos, 64);
+        if (pos != 255u && !stop) {
+            if (STATS) cn.triTests++;
+            if (rt < r.hit.t) { r.hit.t = rt; winner = (int)pos; accepted = true; if (r.anyHit) stop = true; }
+        }
+    }
+    const float wu = __shfl(h.u, winner, 64), wv = __shfl(h.v, winner, 64);
+    const uint32_t wi = (uint32_t)__shfl((int)h.triIndex, winner, 64);
+    if (accepted) { r.hit.u = wu; r.hit.v = wv; r.hit.triIndex = wi; }
+    r.tg.y &= ~taken;
+    if (accepted && r.anyHit) {
+        r.tg.y = 0u; r.ng.y = 0u; r.sp = 0u;
+        if (STATS && r.overflow) cn.overflows++;
+        return true;
+    }
+    return false;
+}
+
 template <bool STATS, class ST>
 PT_DEV bool ray_node_phase(const DScene& S, RayState& r, ST& st, Counters& cn)  // precondition: r.tg.y == 0
 {

@@ -188,6 +188,9 @@ __global__ __launch_bounds__(256, 4) void pt_wf_trace(DScene S, PTWfBuffers B)
 #ifndef PT_WF_TRI_THRESHOLD
 #define PT_WF_TRI_THRESHOLD 0u  // >0: run the triangle phase only when that many lanes have a triangle pending (measured slower: 8: +0 %, 16: -4 %, 32: -12 %); 0 = nested loop
 #endif
+#ifndef PT_WF_GATHER
+#define PT_WF_GATHER 0u         // >0: triangle phases deal (ray, triangle) pairs out to all lanes (wave_tri_gather) once that many lanes have a triangle pending
+#endif
 #ifndef PT_WF_TRACE_BLOCK
 #define PT_WF_TRACE_BLOCK 64u   // threads per workgroup of the refill trace kernel (one wave: a finished wave frees its slot at once)
 #endif
@@ -263,7 +266,15 @@ __global__ __launch_bounds__(PT_WF_TRACE_BLOCK, PT_WF_TRACE_MIN_WAVES) void pt_w
         // ---- traverse until enough lanes have retired (or, once the range is exhausted, until all have)
         const uint32_t stopAt = cursor < nItems ? PT_WF_REFILL : 64u;
         do {
-#if PT_WF_TRI_THRESHOLD > 0
+#if PT_WF_GATHER > 0
+            const bool wantTri = have && rs.tg.y != 0u;
+            const uint32_t nT = (uint32_t)__popcll(__ballot(wantTri));
+            const uint32_t nN = (uint32_t)__popcll(__ballot(have && !wantTri));
+            bool fin = false;
+            if (nT > 0u && (nT >= PT_WF_GATHER || nN == 0u)) fin = wave_tri_gather<STATS>(S, rs, wantTri, xchg, lane, cn);
+            if (have && !fin && rs.tg.y == 0u) fin = ray_node_phase<STATS>(S, rs, st, cn);
+            if (fin) {
+#elif PT_WF_TRI_THRESHOLD > 0
             // phase scheduling: the node phase runs whenever a lane wants it; the (short, sparse) triangle phase only when
             // enough lanes have a triangle pending, or when nobody can do anything else
             const bool wantTri = have && rs.tg.y != 0u;
@@ -282,7 +293,7 @@ __global__ __launch_bounds__(PT_WF_TRACE_BLOCK, PT_WF_TRACE_MIN_WAVES) void pt_w
                     if (myKind == 0u) B.hit[mySlot] = make_float4(rs.hit.t, rs.hit.u, rs.hit.v, pt_asfloat(rs.hit.triIndex));
                     else B.occl[(size_t)(myKind - 1u) * B.numSlots + mySlot] = rs.hit.t < PT_FAR_PLANE ? 1 : 0;
                     have = false;
-#if PT_WF_TRI_THRESHOLD > 0
+#if PT_WF_TRI_THRESHOLD > 0 || PT_WF_GATHER > 0
             }
 #else
                 }
