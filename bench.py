@@ -244,6 +244,18 @@ def main():
                     traffic = rec.get("bytes_per_launch")
             except Exception:
                 traffic = None
+        valu = None
+        vj = os.path.join(ROOT, "profiles", "valu_insts.json")
+        if os.path.exists(vj):
+            try:
+                rec = json.load(open(vj))
+                if rec.get("workload") == args.workload and rec.get("n_gpus", 1) == world and kernel_s > 0:
+                    # second roofline: wave-level VALU instructions per pass (SQ_INSTS_VALU, profiled) against the issue peak
+                    # (256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction) over the kernel time measured NOW
+                    valu = {"wave_insts_per_launch": rec["valu_wave_insts_per_launch"], "issue_peak_per_s": rec["issue_peak_wave_insts_per_s"],
+                            "frac": round(rec["valu_wave_insts_per_launch"] / kernel_s / rec["issue_peak_wave_insts_per_s"], 4)}
+            except Exception:
+                valu = None
         out = {
             "metric": "Mrays/s at 1920x1080, 8 spp", "value": round(main_res["mrays_per_s"], 3), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(main_res["ms_per_step"], 4),
@@ -262,7 +274,8 @@ def main():
                          "algorithmic_bytes_per_launch": round(main_res["alg_bytes_per_launch"]),
                          "counters_per_launch": {k: round(v) for k, v in main_res["counters_per_launch"].items()},
                          "max_stack_depth": main_res["max_stack_depth"],
-                         "note": "rank-0 kernel; working set is Infinity-Cache resident, the path is latency/divergence-bound (DESIGN.md)"},
+                         "valu_issue": valu,
+                         "note": "rank-0 kernel; working set is Infinity-Cache resident; the pass is VALU-issue-bound under divergence (valu_issue.frac, DESIGN.md 5.4)"},
         }
     if not args.no_extra and not distributed:
         extra = {}
