@@ -484,6 +484,11 @@ __global__ __launch_bounds__(256, PT_WF_SHADE_MIN_WAVES) void pt_wf_shade(DScene
     const uint32_t f = B.flags[slot];
     Counters cn = {};
     bool alive = false;
+#ifdef PT_SHADE_DIAG
+    // diagnostics build: wave-level executions of the shade body and lanes active in them (reported in the TLAS counters)
+    if (__any(fl_state(f) != PS_DONE) && (threadIdx.x & 63u) == 0u) cn.tlasNodeVisits++;
+    if (fl_state(f) != PS_DONE) cn.instanceVisits++;
+#endif
     if (fl_state(f) != PS_DONE) alive = shade_slot<STATS>(S, P, tm, B, slot, f, cn);
     if (__any(alive) && (threadIdx.x & 63u) == 0u) B.aliveFlags[iteration] = 1u;     // diagnostics: last iteration anybody needed
     flush_counters<STATS>(cn, B.statRows, vb * 4u + (threadIdx.x >> 6), threadIdx.x & 63u);
