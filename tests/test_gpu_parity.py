@@ -364,3 +364,53 @@ def test_full_size_frame_windows_and_properties(oracle):
     pt.OnRenderImage(seeds[1])
     assert np.array_equal(pt.readback().view(np.uint32), f1.view(np.uint32))
     pt.close()
+
+
+def test_api_error_behaviour():
+    """Every PT* entry point returns 0 or a negative PT_ERR_* code with a message; nothing is rendered on bad input."""
+    import ctypes as C
+    from unity_webgpu_pathtracer_amd import abi, plugin
+    lib = plugin.load_library()
+    ctx = C.c_void_p()
+    assert lib.PTCreate(99, C.byref(ctx)) in (abi.PT_ERR_NO_DEVICE, abi.PT_ERR_INVALID_ARG, abi.PT_ERR_HIP) and not ctx.value   # no such device
+    assert lib.PTCreate(0, C.byref(ctx)) == abi.PT_OK
+    s = scenes.cornell_box()
+    p = scenes.frame_params(s, 64, 64)
+    assert lib.PTRenderPass(ctx, C.byref(p)) == abi.PT_ERR_NO_SCENE and b"PTSetScene" in lib.PTGetLastError()
+    assert lib.PTRenderPass(ctx, None) == abi.PT_ERR_INVALID_ARG
+    assert lib.PTSetScene(ctx, None) == abi.PT_ERR_INVALID_ARG
+    bad = abi.PTSceneDesc()                                        # all NULL
+    assert lib.PTSetScene(ctx, C.byref(bad)) == abi.PT_ERR_INVALID_ARG
+    lib.PTDestroy(ctx)
+
+    pt = PathTracer(s, width=64, height=64)
+    d = pt._bvhScene.desc()
+    d.features |= abi.PT_FEATURE_HAS_TEXTURES                      # keyword on, no data
+    assert lib.PTSetScene(pt.ctx, C.byref(d)) == abi.PT_ERR_INVALID_ARG
+    d = pt._bvhScene.desc()
+    d.bvhNodesBytes = 81                                           # not a multiple of the 80-byte node
+    assert lib.PTSetScene(pt.ctx, C.byref(d)) == abi.PT_ERR_INVALID_ARG
+    d = pt._bvhScene.desc()
+    d.features |= abi.PT_FEATURE_HAS_ENVIRONMENT_TEXTURE
+    assert lib.PTSetScene(pt.ctx, C.byref(d)) == abi.PT_ERR_INVALID_ARG
+    zero = scenes.frame_params(s, 64, 64)
+    zero.OutputWidth = 0
+    assert lib.PTRenderPass(pt.ctx, C.byref(zero)) == abi.PT_ERR_INVALID_ARG
+    huge = scenes.frame_params(s, 64, 64)
+    huge.OutputWidth, huge.OutputHeight = 65536, 65536
+    assert lib.PTRenderPass(pt.ctx, C.byref(huge)) == abi.PT_ERR_INVALID_ARG
+    later = scenes.frame_params(s, 64, 64, current_sample=8)
+    assert lib.PTRenderPassTo(pt.ctx, C.byref(later), C.c_void_p(pt.lib.PTGetFramePointer(pt.ctx, 0)), None) == abi.PT_ERR_INVALID_ARG
+    assert lib.PTRenderPassTo(pt.ctx, C.byref(p), None, None) == abi.PT_ERR_INVALID_ARG
+    assert lib.PTSetSchedule(pt.ctx, 9) == abi.PT_ERR_UNSUPPORTED and lib.PTSetSchedule(pt.ctx, -1) == abi.PT_OK
+    assert lib.PTSetTileOwnership(pt.ctx, 3, 2) == abi.PT_ERR_INVALID_ARG
+    many = scenes.frame_params(s, 64, 64, spp=5000)
+    assert lib.PTSetSchedule(pt.ctx, 1) == abi.PT_OK
+    assert lib.PTRenderPass(pt.ctx, C.byref(many)) == abi.PT_ERR_UNSUPPORTED          # the wavefront packs spp into 12 bits
+    buf = np.zeros(16, np.float32)
+    assert lib.PTReadback(pt.ctx, buf.ctypes.data_as(C.c_void_p), buf.size) == abi.PT_ERR_INVALID_ARG   # no frame yet / too small
+    # a good pass still works after all of that
+    assert lib.PTSetSchedule(pt.ctx, -1) == abi.PT_OK
+    pt.render_pass(pt.params(seed=5))
+    assert np.isfinite(pt.readback()).all()
+    pt.close()
