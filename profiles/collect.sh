@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun) from the repo root:  bash profiles/collect.sh r01
-# Three separate rocprofv3 runs of the same bench command: kernel trace + stats, then one --pmc pass per counter
+# Four separate rocprofv3 runs of the same bench command: kernel trace + stats, then one --pmc pass per counter group
 # (FETCH_SIZE and WRITE_SIZE do not fit one pass; --pmc is never combined with other trace domains).
 set -e
 TAG=${1:-r01}
@@ -9,4 +9,5 @@ CMD="python3 bench.py --steps 4 --warmup 1 --no-extra --no-cpu-baseline --no-alg
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_trace -- $CMD > gpurun_out/${TAG}_trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/${TAG}_fetch -- $CMD > gpurun_out/${TAG}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/${TAG}_write -- $CMD > gpurun_out/${TAG}_write.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d gpurun_out/${TAG}_valu -- $CMD > gpurun_out/${TAG}_valu.log 2>&1
 tail -1 gpurun_out/${TAG}_trace.log | cut -c1-600

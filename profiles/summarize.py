@@ -76,6 +76,22 @@ def main():
         rows = [r for r in csv.DictReader(open(f[0])) if "pt_" in r["Kernel_Name"] and r["Counter_Name"] == counter]
         passes, per_kernel = per_pass(rows, lambda r: float(r["Counter_Value"]))
         pmc[counter] = {"KiB_per_pass": sum(passes) / max(1, len(passes)), "passes": len(passes), "KiB_per_pass_by_kernel": per_kernel}
+    f = glob.glob(os.path.join(base, f"{tag}_valu", "*", "*_counter_collection.csv"))
+    if f:
+        allrows = [r for r in csv.DictReader(open(f[0])) if "pt_" in r["Kernel_Name"]]
+        for counter in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS"):
+            rows = [r for r in allrows if r["Counter_Name"] == counter]
+            passes, per_kernel = per_pass(rows, lambda r: float(r["Counter_Value"]))
+            if passes:
+                pmc[counter] = {"per_pass": sum(passes) / len(passes), "passes": len(passes), "per_pass_by_kernel": per_kernel}
+        if "SQ_INSTS_VALU" in pmc:
+            # the second roofline of bench.py: wave-level VALU instructions against 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles
+            json.dump({"workload": workload, "n_gpus": 1, "passes_profiled": pmc["SQ_INSTS_VALU"]["passes"],
+                       "valu_wave_insts_per_launch": pmc["SQ_INSTS_VALU"]["per_pass"],
+                       "by_kernel": pmc["SQ_INSTS_VALU"]["per_pass_by_kernel"],
+                       "issue_peak_wave_insts_per_s": 256 * 4 * 2.4e9 / 4,
+                       "source": "rocprofv3 --pmc SQ_INSTS_VALU (profiles/collect.sh %s), summed over the kernels of a pass; profiles/%s_pmc.json" % (tag, tag)},
+                      open(os.path.join(ROOT, "profiles", "valu_insts.json"), "w"), indent=1)
     out["pmc"] = pmc
     if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
         fetch = pmc["FETCH_SIZE"]["KiB_per_pass"] * 1024
