@@ -174,6 +174,8 @@ __global__ __launch_bounds__(256, 4) void pt_wf_trace(DScene S, PTWfBuffers B)
 #ifndef PT_WF_RANGE
 #define PT_WF_RANGE 64u         // slots per wave (power of two); small ranges balance load across CUs (measured 64 > 128 > 256)
 #endif
+static_assert(PT_WF_RANGE >= 32u && (PT_WF_RANGE & (PT_WF_RANGE - 1u)) == 0u,
+              "one counter row per trace wave: pt_api.hip sizes statRows for 4 x numSlots/64 rows, of which the trace kernels use rows numSlots/64 .. numSlots/64 + numSlots/PT_WF_RANGE");
 #ifndef PT_WF_REFILL
 #define PT_WF_REFILL 16u        // refill when at least this many lanes are idle
 #endif
