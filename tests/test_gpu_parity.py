@@ -414,3 +414,32 @@ def test_api_error_behaviour():
     pt.render_pass(pt.params(seed=5))
     assert np.isfinite(pt.readback()).all()
     pt.close()
+
+
+def test_c5_4k_64spp_one_rank_of_eight(oracle):
+    """BASELINE.json configs[4] as ONE rank sees it: Sponza-class, 3840x2160, 64 spp per pass, rank 3 of 8.  Owned windows equal
+    the oracle's bits, non-owned pixels are exact zeros, and the rank renders its 1/8 of the paths."""
+    s = scenes.sponza_atrium(tex_size=64)
+    W, H, SPP, rank, world = 3840, 2160, 64, 3, 8
+    pt = PathTracer(s, width=W, height=H, samplesPerPass=SPP, rank=rank, world_size=world)
+    p = pt.params(seed=0xC5C5C5)
+    pt.render_pass(p)
+    f = pt.readback()
+    st = pt.stats()
+    from unity_webgpu_pathtracer_amd import distributed
+    mask = distributed.ownership_mask(W, H, rank, world)
+    assert st.paths == int(mask.sum()) * SPP and abs(mask.mean() - 1.0 / world) < 0.01
+    assert (f[~mask] == 0).all() and (f[mask][:, 3] == 1.0).all() and np.isfinite(f).all()
+    b = oracle.buffers_from_bvhscene(pt._bvhScene)
+    checked = 0
+    for (bx, by) in ((0, 0), (100, 60), (239, 134), (17, 90)):                 # 16x16 blocks; pick the ones this rank owns nearby
+        while (bx + by) % world != rank:
+            bx += 1
+        x0, y0 = bx * 16, by * 16
+        x1, y1 = min(x0 + 16, W), min(y0 + 8, H)
+        r, _ = oracle.render(b, p, window=(x0, y0, x1, y1), tile_rank=rank, tile_world=world)
+        assert mask[y0:y1, x0:x1].all()
+        assert np.array_equal(f[y0:y1, x0:x1].view(np.uint32), r[y0:y1, x0:x1].view(np.uint32)), (x0, y0)
+        checked += 1
+    assert checked == 4
+    pt.close()
