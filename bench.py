@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--schedule", type=int, default=-1, help="-1 auto (default: wavefront, megakernel for <=16-node scenes), 0 megakernel, 1 wavefront, 2/3 variants")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL (default); gloo only to rehearse N>1 on a one-GPU box")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--force-dist", action="store_true", help="rehearsal: run the N>1 code path (process group, per-frame reduce) even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alg-replay", action="store_true", help="profiling runs: skip the untimed full-counter replay (roofline.achieved is then null)")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads reported under 'other_workloads'")
@@ -121,7 +122,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = world > 1 or args.force_dist
+    if args.force_dist and world == 1:
+        os.environ.setdefault("MASTER_PORT", "29655")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

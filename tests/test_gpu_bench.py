@@ -37,3 +37,16 @@ def test_bench_contract_and_two_rank_rehearsal():
     assert two["n_gpus"] == 2 and two["value"] > 0
     assert two["config"]["rays_per_step"] == one["config"]["rays_per_step"]          # strong scaling: same frame, same rays
     assert two["config"]["frame_crc32"] == one["config"]["frame_crc32"] != 0
+
+
+@pytest.mark.gpu
+def test_bench_rccl_code_path_with_one_rank():
+    """The N>1 path with the real backend (nccl = RCCL): process group on the device, per-frame reduce on the context's
+    stream, barriers.  One rank is all a one-GPU box allows RCCL; the frame must equal the plain N=1 frame."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    plain = _last_json(subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + SMALL,
+                                               env=env, timeout=600, stderr=subprocess.STDOUT))
+    forced = _last_json(subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist"] + SMALL,
+                                                env=env, timeout=600, stderr=subprocess.STDOUT))
+    assert forced["config"]["frame_crc32"] == plain["config"]["frame_crc32"] != 0
+    assert "RCCL" in forced["config"]["sharding"] and forced["value"] > 0
