@@ -103,6 +103,23 @@ def main():
                         stat_names=np.array(sorted(st.as_dict())))
     print(f"frame_zoo_env: mean {img[..., :3].mean():.5f}")
 
+    # presentation blit and ingestion: regression pins of the restatements (tests/test_present.py, tests/test_ingest.py)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_present
+    import test_ingest
+    from unity_webgpu_pathtracer_amd import ingest
+    f = test_present._hdr_frame(24, 10, seed=3)
+    outs = {}
+    for i, (mode, srgb, kw) in enumerate(test_present.CASES):
+        outs[f"case{i}"] = pyoracle.present(test_present._params(24, 10, mode, srgb, **kw), f)
+    np.savez_compressed(os.path.join(HERE, "present_cases.npz"), frame=f, **outs)
+    meshes = test_ingest._mesh_zoo()
+    descs, total, keep = ingest.mesh_descs(meshes)
+    pos, attrs = pyoracle.process_meshes(list(descs), total)
+    np.savez_compressed(os.path.join(HERE, "ingest_mesh_zoo.npz"), positions=pos[::7], attrs=attrs.view(np.uint8).reshape(total, 128)[::5],
+                        total=total)
+    print("present_cases, ingest_mesh_zoo written")
+
 
 if __name__ == "__main__":
     main()

@@ -90,6 +90,17 @@ def test_oracle_process_mesh_matches_numpy(oracle):
     assert start == total
 
 
+def test_golden_mesh_zoo(oracle):
+    """Regression pin of the restatement (tests/golden/make_golden.py): a sample of the mesh-zoo outputs, bit for bit."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ingest_mesh_zoo.npz"))
+    meshes = _mesh_zoo()
+    descs, total, keep = ingest.mesh_descs(meshes)
+    pos, attrs = oracle.process_meshes(list(descs), total)
+    assert total == int(g["total"])
+    assert np.array_equal(pos[::7].view(np.uint32), g["positions"].view(np.uint32))
+    assert np.array_equal(attrs.view(np.uint8).reshape(total, 128)[::5], g["attrs"])
+
+
 def test_oracle_copy_texture_data_matches_packer(oracle):
     imgs = [scenes.tex_checker(16, (0.9, 0.9, 0.9, 1), (0.2, 0.2, 0.25, 0.5), 4), scenes.tex_noise(8, (0, 0.9, 0, 1), (0, 0.2, 1, 1), seed=3)]
     imgs.append(np.random.RandomState(1).uniform(0, 1, (5, 11, 4)).astype(np.float32))      # not a multiple of the 8x8 group

@@ -76,6 +76,15 @@ def test_oracle_present_matches_numpy(oracle, mode, srgb, kw):
     assert (got[..., 3] == 1.0).all()
 
 
+def test_golden_cases(oracle):
+    """Regression pin of the restatement (tests/golden/make_golden.py)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "present_cases.npz"))
+    for i, (mode, srgb, kw) in enumerate(CASES):
+        got = oracle.present(_params(24, 10, mode, srgb, **kw), g["frame"])
+        assert np.array_equal(got.view(np.uint32), g[f"case{i}"].view(np.uint32)), i
+
+
 def test_known_answers(oracle):
     f = np.ones((1, 4, 4), dtype=np.float32)
     f[0, :, :3] = np.array([[0.0] * 3, [0.25] * 3, [1.0] * 3, [3.0] * 3], dtype=np.float32)
