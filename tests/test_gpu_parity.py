@@ -443,3 +443,25 @@ def test_c5_4k_64spp_one_rank_of_eight(oracle):
         checked += 1
     assert checked == 4
     pt.close()
+
+
+@pytest.mark.parametrize("schedule", [0, 1])
+def test_all_keywords_together(oracle, schedule):
+    """HAS_TLAS + HAS_ENVIRONMENT_TEXTURE + HAS_LIGHTS (+ thin lens, firefly filter, map rotation): every shader keyword of
+    PathTracer.compute:6-9 on at once."""
+    s = scenes.instanced_scene(count=9, detail=8)
+    s.environment_texture = scenes.sky_environment(48, 24, sun_dir=(-0.3, 0.6, 0.4))
+    s.environment_map_rotation = 0.35
+    s.environment_intensity = 0.8
+    s.camera.aperture, s.camera.focal_length = 0.05, 8.0
+    assert s.features & 0xD == 0xD
+    pt = PathTracer(s, width=120, height=72, samplesPerPass=3, fireflyFilter=True, maxFireflyLuminance=6.0, schedule=schedule)
+    pt.set_stats_level(1)
+    p = pt.params(seed=0xA11)
+    pt.render_pass(p)
+    gpu = pt.readback()
+    ref, st = _oracle_frame(oracle, pt, p, shadow_any_hit=True)
+    _, nbad = _compare(gpu, ref, f"all keywords, schedule {schedule}")
+    assert nbad == 0
+    _stats_equal(pt.stats(), st, ALL_COUNTERS)
+    pt.close()
