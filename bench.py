@@ -287,7 +287,7 @@ def main():
         for name in WORKLOADS:
             if name == args.workload:
                 continue
-            r = run_workload(name, max(2, args.steps // 2), 1, full=False)
+            r = run_workload(name, max(4, args.steps), max(2, args.warmup), full=False)
             r["_pt"].close()
             extra[name] = {"mrays_per_s": round(r["mrays_per_s"], 3), "ms_per_step": round(r["ms_per_step"], 4), "tris": r["tris"],
                            "schedule": r["schedule"]}
