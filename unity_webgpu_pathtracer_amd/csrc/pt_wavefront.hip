@@ -502,9 +502,12 @@ template <bool STATS, bool TLAS>
 __global__ __launch_bounds__(256, 2) void pt_wf_cleanup(DScene S, PTFrameParams P, PTTileMap tm, PTWfBuffers B)
 {
     __shared__ uint2 s_stack[PT_LDS_STACK][256];
-    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t f = B.flags[slot];
     Counters cn = {};
+    // a few resident workgroups stride over the slot blocks: almost every block is finished already, and scanning 256 flag
+    // words is cheaper than scheduling a 24-KB-LDS workgroup for them
+    for (uint32_t blk = blockIdx.x; blk < (B.numSlots >> 8); blk += gridDim.x) {
+    const uint32_t slot = blk * 256u + threadIdx.x;
+    const uint32_t f = B.flags[slot];
     if (__any(fl_state(f) != PS_DONE)) {
         if (fl_state(f) != PS_DONE) {
             uint32_t px, py;
@@ -546,6 +549,7 @@ __global__ __launch_bounds__(256, 2) void pt_wf_cleanup(DScene S, PTFrameParams 
             B.flags[slot] = pack_flags(r);
             B.color[slot] = f4(r.color, 0.0f);
         }
+    }
     }
     flush_counters<STATS>(cn, B.statRows, blockIdx.x * 4u + (threadIdx.x >> 6), threadIdx.x & 63u);
 }
@@ -654,12 +658,13 @@ hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const fl
         else hipLaunchKernelGGL(pt_wf_shade<false>, dim3(nb), dim3(256), 0, stream, S, P, tm, B, it);
         launches += 2;
     }
+    const uint32_t cleanupBlocks = nb < 1024u ? nb : 1024u;          // 256 CUs x 4 workgroups; each strides over the slot blocks
     if (tlas) {
-        if (fullStats) hipLaunchKernelGGL((pt_wf_cleanup<true, true>), dim3(nb), dim3(256), 0, stream, S, P, tm, B);
-        else hipLaunchKernelGGL((pt_wf_cleanup<false, true>), dim3(nb), dim3(256), 0, stream, S, P, tm, B);
+        if (fullStats) hipLaunchKernelGGL((pt_wf_cleanup<true, true>), dim3(cleanupBlocks), dim3(256), 0, stream, S, P, tm, B);
+        else hipLaunchKernelGGL((pt_wf_cleanup<false, true>), dim3(cleanupBlocks), dim3(256), 0, stream, S, P, tm, B);
     } else {
-        if (fullStats) hipLaunchKernelGGL((pt_wf_cleanup<true, false>), dim3(nb), dim3(256), 0, stream, S, P, tm, B);
-        else hipLaunchKernelGGL((pt_wf_cleanup<false, false>), dim3(nb), dim3(256), 0, stream, S, P, tm, B);
+        if (fullStats) hipLaunchKernelGGL((pt_wf_cleanup<true, false>), dim3(cleanupBlocks), dim3(256), 0, stream, S, P, tm, B);
+        else hipLaunchKernelGGL((pt_wf_cleanup<false, false>), dim3(cleanupBlocks), dim3(256), 0, stream, S, P, tm, B);
     }
     if (orderAfter && (e = hipStreamWaitEvent(stream, orderAfter, 0)) != hipSuccess) return e;
     if (zeroOutputFirst &&
