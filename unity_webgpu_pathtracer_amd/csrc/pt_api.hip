@@ -52,7 +52,7 @@ struct PTContext {
     int rank = 0, world = 1;
     int statsLevel = 0;
     int schedule = -1;                          // -1 auto (default), 0 megakernel, 1 wavefront + refill trace, 2, 3: see PTSetSchedule
-    unsigned long long* dStats = nullptr;       // 14 counters, PTStats order
+    unsigned long long* dStats = nullptr;       // 16 counters, PTStats order
     bool profiling = false;
     std::vector<EventPair> pending;             // recorded, not yet read
     std::vector<EventPair> freeEvents;

@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256) void pt_wf_resolve(PTFrameParams P, PTTileMap 
     flush_counters<false>(cn, B.statRows, blockIdx.x * 4u + (threadIdx.x >> 6), threadIdx.x & 63u);
 }
 
-// fold the per-wave rows into the context's 14 counters (PTStats order) and clear them
+// fold the per-wave rows into the context's 16 counters (PTStats order) and clear them
 __global__ __launch_bounds__(256) void pt_wf_fold_rows(unsigned long long* rows, uint32_t numRows, unsigned long long* gstats)
 {
     unsigned long long acc[PT_NUM_COUNTERS] = {};
