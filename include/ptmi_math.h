@@ -44,6 +44,7 @@ PT_HD float pt_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); 
 PT_HD float pt_sqrt(float x) { return __builtin_sqrtf(x); }
 PT_HD float pt_abs(float x) { return __builtin_fabsf(x); }
 PT_HD float pt_floor(float x) { return __builtin_floorf(x); }
+PT_HD float pt_ceil(float x) { return __builtin_ceilf(x); }
 PT_HD float pt_rint(float x) { return __builtin_rintf(x); }          /* ties-to-even */
 /* HLSL min/max: if one operand is NaN the other is returned (IEEE minNum/maxNum). */
 PT_HD float pt_min(float a, float b) { return __builtin_fminf(a, b); }
@@ -54,6 +55,21 @@ PT_HD float pt_rcp(float x) { return 1.0f / x; }                      /* HLSL rc
 PT_HD float pt_rsqrt(float x) { return 1.0f / pt_sqrt(x); }           /* HLSL rsqrt */
 PT_HD float pt_lerp(float a, float b, float t) { return a + t * (b - a); }
 PT_HD int   pt_isnan(float x) { return x != x; }
+
+/* util/texture.hlsl:41-48 wraps a texture coordinate with `while (u > 1) u -= 1; while (u < 0) u += 1;`.
+ * Below 2^24 every intermediate u -+ 1 of those loops is exact (the result is a multiple of ulp(u) of smaller
+ * magnitude) except possibly the last step of the upward loop, so ONE subtraction / addition of the step count gives
+ * the loops' result bit for bit: k = ceil(u) - 1 steps down for u > 1, k = ceil(-u) steps up for u < 0.
+ * From 2^24 on (and for +-inf) u -+ 1 == u and the reference's loops never terminate (a GPU hang / TDR): those
+ * inputs are DEFINED here as 0.  NaN fails both loop conditions and passes through.
+ * tests/test_math.py checks this against the literal loops. */
+PT_HD float pt_wrap01(float u)
+{
+    if (pt_abs(u) >= 16777216.0f) return 0.0f;
+    if (u > 1.0f) return u - (pt_ceil(u) - 1.0f);
+    if (u < 0.0f) return u + pt_ceil(-u);
+    return u;
+}
 
 /* float -> integer conversions with D3D/WebGPU semantics (truncate, saturate, NaN -> 0);
  * C leaves the out-of-range cases undefined, gfx950 v_cvt saturates, x86 does not. */

@@ -615,6 +615,10 @@ inline f4 SampleTexture(Ctx& c, int32_t textureIndex, f2 uv, bool linearSample) 
     uint32_t width = c.S->tex[d + 0], height = c.S->tex[d + 1], offset = c.S->tex[d + 2];
     c.st.texDescriptorFetches++;
     float u = uv.x, v = uv.y;
+    // :41-48, the literal loops.  They never terminate for |u| >= 2^24 or +-inf (u -+ 1 == u): such inputs are DEFINED
+    // as 0 in this project (oracle and kernel; ptmi_math.h pt_wrap01 is the kernel's closed form of the same loops).
+    if (pt_abs(u) >= 16777216.0f) u = 0.0f;
+    if (pt_abs(v) >= 16777216.0f) v = 0.0f;
     while (u > 1.0f) u -= 1.0f;
     while (v > 1.0f) v -= 1.0f;
     while (u < 0.0f) u += 1.0f;
@@ -1246,8 +1250,14 @@ f3 PathTrace(Ctx& c, Ray ray, uint32_t& rng)
 
         if (rayDepth >= maxRayBounces) break;
 
+        // :84-85 is one boolean expression.  HLSL before HLSL 2021 does NOT short-circuit && / || (they are
+        // component-wise operators: every operand is evaluated, side effects included).  FXC is in the reference's
+        // pipeline (its own workaround comment, util/bvh.hlsl:133-135) and PathTracer.compute has no `#pragma use_dxc`
+        // / -HV 2021, so RandomFloat(rngState) is drawn on EVERY bounce that reaches this line -- for OPAQUE and MASK
+        // materials too -- and its value is only USED for BLEND.  (Nothing here can execute HLSL: parity unpinned.)
+        const float alphaRnd = RandomFloat(rng);
         if ((material.alphaMode == (float)PT_ALPHA_MODE_MASK && material.opacity < material.alphaCutoff) ||
-            (material.alphaMode == (float)PT_ALPHA_MODE_BLEND && RandomFloat(rng) > material.opacity)) {
+            (material.alphaMode == (float)PT_ALPHA_MODE_BLEND && alphaRnd > material.opacity)) {
             scatterL = ray.direction;
             rayDepth--;                                   // uint wrap at 0, undone by the loop's ++ (:88)
         } else {
@@ -1524,6 +1534,14 @@ float oracle_math(int fn, float x, float y)
     case 9: return pt_rcp(x);
     case 10: return pt_atan2(x, y);
     case 11: return pt_fmod(x, y);
+    case 12: return pt_wrap01(x);
+    case 13: {                                    // the literal loops of util/texture.hlsl:41-48 (with this project's guard)
+        float u = x;
+        if (pt_abs(u) >= 16777216.0f) u = 0.0f;
+        while (u > 1.0f) u -= 1.0f;
+        while (u < 0.0f) u += 1.0f;
+        return u;
+    }
     default: return 0.0f;
     }
 }

@@ -61,7 +61,7 @@ int oracle_trace(const PTSceneDesc* scene, const OracleRay* rays, uint64_t n, fl
 
 /* Scalar entry points for unit tests. */
 float    oracle_random_float(uint32_t* state);                       /* util/random.hlsl:12-16 */
-float    oracle_math(int fn, float x, float y);                      /* ptmi_math.h: 0 sin 1 cos 2 log 3 log2 4 exp2 5 pow 6 acos 7 asin 8 sqrt 9 rcp 10 atan2(x = y-arg, y = x-arg) 11 fmod */
+float    oracle_math(int fn, float x, float y);                      /* ptmi_math.h: 0 sin 1 cos 2 log 3 log2 4 exp2 5 pow 6 acos 7 asin 8 sqrt 9 rcp 10 atan2(x = y-arg, y = x-arg) 11 fmod 12 wrap01 (closed form) 13 wrap01 (literal loops) */
 /* Evaluates / samples the Disney BSDF in isolation (util/brdf.hlsl:114-340).
  * material: 32 floats of MaterialData (no textures); V, N, L world-space; returns f via out[0..2], pdf out[3]. */
 void     oracle_eval_brdf(const float* material, const float* V, const float* N, const float* L, float eta, float* out);

@@ -167,7 +167,7 @@ def test_nan_nee_ray_is_a_cheap_miss(oracle, schedule):
     s = scenes.sponza_atrium(tex_size=4, detail=0.15)
     pt = PathTracer(s, width=8, height=8, samplesPerPass=1, schedule=schedule)
     pt.set_stats_level(1)
-    p = pt.params(seed=0xED3B3E)
+    p = pt.params(seed=0xA79B11)        # see tests/test_oracle.py::test_nan_nee_ray_counting_variant
     pt.render_pass(p)
     gpu = pt.readback()
     faithful, sf = _oracle_frame(oracle, pt, p)

@@ -94,3 +94,20 @@ def test_rng_top_states_round_to_one(lib):
     assert np.float32(0xFFFFFF80) / np.float32(4294967296.0) == 1.0
     # per-pixel seed example of SURVEY.md Appendix D: W = 256, pixel (10, 3), CurrentSample 0
     assert (3 * 256 + 10) * (0 + 1) + 0x12345678 == 0x12345982
+
+
+def test_texture_wrap_closed_form_equals_the_reference_loops(lib):
+    """util/texture.hlsl:41-48 wraps with `while (u > 1) u -= 1; while (u < 0) u += 1`.  The kernels use the closed form
+    pt_wrap01 (bounded cost, no hang for huge / infinite uv); it must give the literal loops' result bit for bit."""
+    rng = np.random.RandomState(5)
+    vals = np.concatenate([
+        rng.uniform(-8, 8, 4000), rng.uniform(-3000, 3000, 3000), rng.normal(0, 1e-6, 500), rng.uniform(-2e5, 2e5, 300),
+        np.array([0.0, -0.0, 1.0, -1.0, 2.0, -2.0, 1.0000001, -1.0000001, 0.99999994, -1e-10, 1e-10, 3.5, -2.5, 4096.0, -4096.0,
+                  16777215.0, -16777215.0, 16777216.0, -16777216.0, 3e7, -3e7, 1e30, float("inf"), float("-inf")]),
+        np.arange(-40, 40) + np.float32(2 ** -23), np.arange(-40, 40) - np.float32(2 ** -23),
+    ]).astype(np.float32)
+    closed = _apply(lib, 12, vals)
+    loops = _apply(lib, 13, vals)
+    assert np.array_equal(closed.view(np.uint32), loops.view(np.uint32))
+    assert ((closed >= 0) & (closed <= 1)).all()
+    assert np.isnan(lib.oracle_math(12, float("nan"), 0.0)) and np.isnan(lib.oracle_math(13, float("nan"), 0.0))

@@ -609,11 +609,8 @@ PT_DEV v4 sample_texture(const DScene& S, int32_t textureIndex, v2 uv, Counters&
     uint32_t dsc = (uint32_t)textureIndex * 4u;
     uint32_t width = S.tex[dsc + 0], height = S.tex[dsc + 1], offset = S.tex[dsc + 2];
     if (STATS) cn.texDescFetches++;
-    float u = uv.x, v = uv.y;
-    while (u > 1.0f) u -= 1.0f;
-    while (v > 1.0f) v -= 1.0f;
-    while (u < 0.0f) u += 1.0f;
-    while (v < 0.0f) v += 1.0f;
+    // util/texture.hlsl:41-48: the reference's +-1 wrap loops in closed form (bit-identical, and bounded: ptmi_math.h)
+    const float u = pt_wrap01(uv.x), v = pt_wrap01(uv.y);
     float tu = u * ((float)width - 1.0f);
     float tv = v * ((float)height - 1.0f);
     uint32_t tx = pt_f2u(tu), ty = pt_f2u(tv);
@@ -1349,9 +1346,13 @@ PT_DEV void path_step(const DScene& S, const PTFrameParams& P, PathRegs& r, cons
                 r.state = PS_ENDING;
             } else {
                 v3 scatterL;
-                bool skip = false;
-                if (material.alphaMode == (float)PT_ALPHA_MODE_MASK && material.opacity < material.alphaCutoff) skip = true;
-                else if (material.alphaMode == (float)PT_ALPHA_MODE_BLEND && rnd(r.rng) > material.opacity) skip = true;
+                // util/pathtrace.hlsl:84-85 is ONE boolean expression: (MASK && opacity < cutoff) || (BLEND && RandomFloat() > opacity).
+                // HLSL (before HLSL 2021; FXC is in the reference's pipeline, util/bvh.hlsl:133-135, and PathTracer.compute
+                // selects neither DXC nor -HV 2021) does not short-circuit && / ||: every operand is evaluated, side effects
+                // included, so RandomFloat is drawn on EVERY bounce that reaches this point, whatever the alpha mode.
+                const float alphaRnd = rnd(r.rng);
+                const bool skip = (material.alphaMode == (float)PT_ALPHA_MODE_MASK && material.opacity < material.alphaCutoff) ||
+                                  (material.alphaMode == (float)PT_ALPHA_MODE_BLEND && alphaRnd > material.opacity);
                 bool advance = true;
                 if (skip) {
                     scatterL = r.rd;                             // rayDepth-- then ++: depth unchanged (util/pathtrace.hlsl:85-88)
