@@ -1,13 +1,16 @@
 #!/bin/bash
-# Run ON THE GPU BOX (through gpurun) from the repo root:  bash profiles/collect.sh r01
-# Four separate rocprofv3 runs of the same bench command: kernel trace + stats, then one --pmc pass per counter group
-# (FETCH_SIZE and WRITE_SIZE do not fit one pass; --pmc is never combined with other trace domains).
+# Run ON THE GPU BOX (through gpurun) from the repo root:  bash profiles/collect.sh r02
+# Separate rocprofv3 runs of the same bench command: kernel trace + stats, then one --pmc pass per counter group
+# (FETCH_SIZE and WRITE_SIZE do not fit one pass; --pmc is never combined with other trace domains; the program itself
+# follows `--`).  profiles/summarize.py turns the CSVs into the summaries kept under profiles/.
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 export TMPDIR=/tmp
 CMD="python3 bench.py --steps 4 --warmup 1 --no-extra --no-cpu-baseline --no-alg-replay"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_trace -- $CMD > gpurun_out/${TAG}_trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/${TAG}_fetch -- $CMD > gpurun_out/${TAG}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/${TAG}_write -- $CMD > gpurun_out/${TAG}_write.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d gpurun_out/${TAG}_valu -- $CMD > gpurun_out/${TAG}_valu.log 2>&1
+# where the wave-cycles go: WAIT_ANY (parked on s_waitcnt) + WAIT_INST_ANY (issue stall) + ACTIVE_INST_ANY ~ WAVE_CYCLES (quad-cycles)
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU --kernel-trace --output-format csv -d gpurun_out/${TAG}_wait -- $CMD > gpurun_out/${TAG}_wait.log 2>&1
 tail -1 gpurun_out/${TAG}_trace.log | cut -c1-600
