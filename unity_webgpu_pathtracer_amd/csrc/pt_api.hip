@@ -110,8 +110,9 @@ int ensure_wavefront(PTContext* c, PTContext::WfSet& set, uint32_t numSlots, uin
     const size_t n = numSlots;
     const uint32_t numRows = 4u * (numSlots >> 6);
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t spillBytes = n * (size_t)(PT_BVH_STACK_SIZE - PT_WF_LDS_STACK) * sizeof(uint2);
     size_t total = align(n * 4) * 2 + align(n * 16) * 13 + align(n * 2) + align((size_t)maxIterations * 4) +
-                   align((size_t)numRows * 16 * 8) + align(8 * 32 * 4);
+                   align((size_t)numRows * 16 * 8) + align(8 * 32 * 4) + align(spillBytes);
     if (set.arena && set.arenaBytes < total) { hipFree(set.arena); set.arena = nullptr; set.arenaBytes = 0; }
     if (!set.arena) {
         HIP_TRY(hipMalloc(&set.arena, total));
@@ -128,6 +129,7 @@ int ensure_wavefront(PTContext* c, PTContext::WfSet& set, uint32_t numSlots, uin
     B.aliveFlags = (uint32_t*)carve((size_t)maxIterations * 4);
     B.statRows = (unsigned long long*)carve((size_t)numRows * 16 * 8);
     B.chunkHeads = (uint32_t*)carve(8 * 32 * 4);
+    B.stackSpill = (uint2*)carve(spillBytes);
     {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, c->device));

@@ -120,26 +120,44 @@ PT_DEV float rnd(uint32_t& s) { return pt_random_float(&s); }
 #endif
 #define PT_SPILL_STACK (PT_BVH_STACK_SIZE - PT_LDS_STACK)
 
-template <int LDSN>
+// GSPILL = true: entries beyond the LDS part go to a slab in HBM (gbase + gidx * (32 - LDSN)) instead of a private
+// array.  A private array that is indexed dynamically lives in scratch memory, and a kernel that declares ANY scratch
+// makes the dispatcher allocate a scratch wave slot per wave: for the refill trace kernel that allocation, not registers
+// or LDS, was what limited the waves in flight (SPI_RA_TMP_STALL_CSN 1.7e9 vs SPI_RA_WAVE_SIMD_FULL_CSN 1.9e7 per five
+// passes; removing the 192-byte array: +8 % end to end).  The slab is touched only by rays deeper than LDSN entries.
+template <int LDSN, bool GSPILL = false>
 struct TravStackT {
     static constexpr uint32_t kLds = LDSN;
+    static constexpr bool kGlobalSpill = GSPILL;
     uint2* lds;                 // &smem[0][threadIdx.x]; entry stride = blockDim.x
     uint32_t stride;
-    uint2 spill[PT_BVH_STACK_SIZE - LDSN];
+    uint2 spill[GSPILL ? 1 : PT_BVH_STACK_SIZE - LDSN];
+    uint2* gbase;               // GSPILL: slab base (wave-uniform)
+    uint32_t gidx;              // GSPILL: this lane's row in the slab
 };
 typedef TravStackT<PT_LDS_STACK> TravStack;
+
+// The slab address is formed where it is used (the empty asm keeps the compiler from hoisting the 64-bit address out of the
+// traversal loop, where it would occupy -- and at 64 VGPRs spill -- two registers for a path that almost never runs).
+PT_DEV size_t spill_row(uint32_t gidx) { asm volatile("" : "+v"(gidx)); return (size_t)gidx; }
 
 template <class ST>
 PT_DEV void stack_push(ST& st, uint32_t sp, uint2 v)
 {
     if (sp < ST::kLds) st.lds[sp * st.stride] = v;
-    else if (sp < PT_BVH_STACK_SIZE) st.spill[sp - ST::kLds] = v;
+    else if (sp < PT_BVH_STACK_SIZE) {
+        if (ST::kGlobalSpill) st.gbase[spill_row(st.gidx) * (PT_BVH_STACK_SIZE - ST::kLds) + (sp - ST::kLds)] = v;
+        else st.spill[ST::kGlobalSpill ? 0u : sp - ST::kLds] = v;
+    }
 }
 template <class ST>
 PT_DEV uint2 stack_pop(ST& st, uint32_t sp)
 {
     if (sp < ST::kLds) return st.lds[sp * st.stride];
-    if (sp < PT_BVH_STACK_SIZE) return st.spill[sp - ST::kLds];
+    if (sp < PT_BVH_STACK_SIZE) {
+        if (ST::kGlobalSpill) return st.gbase[spill_row(st.gidx) * (PT_BVH_STACK_SIZE - ST::kLds) + (sp - ST::kLds)];
+        return st.spill[ST::kGlobalSpill ? 0u : sp - ST::kLds];
+    }
     return make_uint2(0u, 0u);
 }
 
@@ -199,13 +217,11 @@ struct TraceHit {
     uint32_t triIndex;  // hit.triIndex (primitive index from the triangle record)
 };
 
-// util/bvh.hlsl:23-59
-PT_DEV void intersect_triangle(const float4* __restrict__ tris, uint32_t triAddr, v3 o, v3 d, TraceHit& hit)
+// util/bvh.hlsl:23-59 on the three 16-byte rows of a triangle record.  TMIN = 1e-4 (util/bvh.hlsl:47); the HAS_TLAS
+// variant accepts distance > 0 (util/tlas.hlsl:47).  Returns true when the hit was accepted.
+template <bool TLAS_EPS>
+PT_DEV bool intersect_triangle_rows(float4 t0, float4 t1, float4 t2, uint32_t indexOffset, v3 o, v3 d, TraceHit& hit)
 {
-    // all 48 bytes are requested before the first use, so the whole test costs ONE memory round trip
-    // (left to itself hipcc sinks the v0 load under the determinant test: two dependent round trips)
-    float4 t0 = tris[triAddr + 0], t1 = tris[triAddr + 1], t2 = tris[triAddr + 2];
-    asm volatile("" : "+v"(t0.x), "+v"(t1.x), "+v"(t2.x), "+v"(t2.w));
     v3 e2 = mk3(t0.x, t0.y, t0.z), e1 = mk3(t1.x, t1.y, t1.z), v0 = mk3(t2.x, t2.y, t2.z);
     v3 r = cross3(d, e2);
     float a = dot3(e1, r);
@@ -218,14 +234,78 @@ PT_DEV void intersect_triangle(const float4* __restrict__ tris, uint32_t triAddr
             float v = f * dot3(d, q);
             if (v >= 0.0f && u + v <= 1.0f) {
                 float dist = f * dot3(e2, q);
-                if (dist > 0.0001f && dist < hit.t) {
+                if (dist > (TLAS_EPS ? 0.0f : 0.0001f) && dist < hit.t) {
                     hit.u = u; hit.v = v;
-                    hit.triIndex = pt_asuint(t2.w);
+                    hit.triIndex = indexOffset + pt_asuint(t2.w);
                     hit.t = dist;
+                    return true;
                 }
             }
         }
     }
+    return false;
+}
+
+PT_DEV void intersect_triangle(const float4* __restrict__ tris, uint32_t triAddr, v3 o, v3 d, TraceHit& hit)
+{
+    // all 48 bytes are requested before the first use, so the whole test costs ONE memory round trip
+    // (left to itself hipcc sinks the v0 load under the determinant test: two dependent round trips)
+    float4 t0 = tris[triAddr + 0], t1 = tris[triAddr + 1], t2 = tris[triAddr + 2];
+    asm volatile("" : "+v"(t0.x), "+v"(t1.x), "+v"(t2.x), "+v"(t2.w));
+    intersect_triangle_rows<false>(t0, t1, t2, 0u, o, d, hit);
+}
+
+// ---- the node visit of util/bvh.hlsl:150-176, shared by EVERY traversal variant in this file --------------------------
+// cwbvh_pick_child: take the nearest hit child off the node group, push what is left, return the child's node index.
+template <bool STATS, class ST>
+PT_DEV uint32_t cwbvh_pick_child(uint2& ng, uint32_t octinv4, uint32_t& sp, bool& overflow, ST& st, Counters& cn)
+{
+    const uint32_t mask = ng.y;
+    const uint32_t childBitIndex = 31u - (uint32_t)__clz((int)mask);
+    const uint32_t childNodeBaseIndex = ng.x;
+    ng.y &= ~(1u << childBitIndex);
+    if (ng.y > 0x00FFFFFFu) {
+        stack_push(st, sp, ng);
+        if (sp >= PT_BVH_STACK_SIZE) overflow = true;
+        sp++;
+        if (STATS) cn.maxStack = sp > cn.maxStack ? sp : cn.maxStack;
+    }
+    const uint32_t slotIndex = (childBitIndex - 24u) ^ (octinv4 & 255u);
+    const uint32_t relativeIndex = (uint32_t)__popc(mask & ~(0xFFFFFFFFu << slotIndex));
+    return childNodeBaseIndex + relativeIndex;
+}
+// cwbvh_apply_node: test the node's eight children and form the new node / triangle groups.
+template <bool STATS>
+PT_DEV void cwbvh_apply_node(v3 o, v3 invDir, uint32_t octinv4, float tmax, uint4 n0, uint4 n1, uint4 n2, uint4 n3, uint4 n4,
+                             uint2& ng, uint2& tg, Counters& cn)
+{
+    const uint32_t hitmask = cwbvh_node_hitmask(o, invDir, octinv4, tmax, n0, n1, n2, n3, n4);
+    if (STATS) cn.nodeVisits++;
+    ng.x = n1.x;
+    ng.y = (hitmask & 0xFF000000u) | (n0.w >> 24);
+    tg.x = n1.y;
+    tg.y = hitmask & 0x00FFFFFFu;
+}
+// cwbvh_visit_node = pick + fetch (five 16-byte rows, requested together) + apply.  nodeOffset: HAS_TLAS instance base.
+template <bool STATS, class ST>
+PT_DEV void cwbvh_visit_node(const uint4* __restrict__ nodes, uint32_t nodeOffset, v3 o, v3 invDir, uint32_t octinv4, float tmax,
+                             uint2& ng, uint2& tg, uint32_t& sp, bool& overflow, ST& st, Counters& cn)
+{
+    const uint32_t childNodeIndex = cwbvh_pick_child<STATS>(ng, octinv4, sp, overflow, st, cn);
+    const uint4* np = nodes + (size_t)(nodeOffset + childNodeIndex) * 5;
+    uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+#ifdef PT_EXP_EXTRA_LOAD
+    {   // EXPERIMENT: TA sensitivity -- one more 16-byte row request per node visit (result unused but waited for)
+        uint4 x;
+        asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(x) : "v"(np + 2) : "memory");
+        asm volatile("" :: "v"(x.x));
+    }
+#endif
+#ifdef PT_EXP_EXTRA_VALU
+#pragma unroll
+    for (int i = 0; i < PT_EXP_EXTRA_VALU; ++i) asm volatile("v_mov_b32 %0, %0" : "+v"(n0.x));   // EXPERIMENT: VALU-issue sensitivity
+#endif
+    cwbvh_apply_node<STATS>(o, invDir, octinv4, tmax, n0, n1, n2, n3, n4, ng, tg, cn);
 }
 
 // util/bvh.hlsl:126-199 for one lane.  ANYHIT = shadow ray: stops at the first accepted triangle
@@ -250,27 +330,7 @@ PT_DEV void traverse_cwbvh(const DScene& S, v3 o, v3 d, bool anyHit, TraceHit& h
     bool overflow = false;
     while (true) {
         if (ng.y > 0x00FFFFFFu) {
-            uint32_t mask = ng.y;
-            uint32_t childBitIndex = 31u - (uint32_t)__clz((int)mask);
-            uint32_t childNodeBaseIndex = ng.x;
-            ng.y &= ~(1u << childBitIndex);
-            if (ng.y > 0x00FFFFFFu) {
-                stack_push(st, sp, ng);
-                if (sp >= PT_BVH_STACK_SIZE) overflow = true;
-                sp++;
-                if (STATS) cn.maxStack = sp > cn.maxStack ? sp : cn.maxStack;
-            }
-            uint32_t slotIndex = (childBitIndex - 24u) ^ (octinv4 & 255u);
-            uint32_t relativeIndex = (uint32_t)__popc(mask & ~(0xFFFFFFFFu << slotIndex));
-            uint32_t childNodeIndex = childNodeBaseIndex + relativeIndex;
-            const uint4* np = S.nodes + (size_t)childNodeIndex * 5;
-            uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-            uint32_t hitmask = cwbvh_node_hitmask(o, invDir, octinv4, hit.t, n0, n1, n2, n3, n4);
-            if (STATS) cn.nodeVisits++;
-            ng.x = n1.x;
-            ng.y = (hitmask & 0xFF000000u) | (n0.w >> 24);
-            tg.x = n1.y;
-            tg.y = hitmask & 0x00FFFFFFu;
+            cwbvh_visit_node<STATS>(S.nodes, 0u, o, invDir, octinv4, hit.t, ng, tg, sp, overflow, st, cn);
         } else {
             tg = ng;
             ng = make_uint2(0u, 0u);
@@ -317,29 +377,7 @@ PT_DEV bool intersect_triangle_inst(const float4* __restrict__ tris, uint32_t tr
 {
     float4 t0 = tris[triAddr + 0], t1 = tris[triAddr + 1], t2 = tris[triAddr + 2];
     asm volatile("" : "+v"(t0.x), "+v"(t1.x), "+v"(t2.x), "+v"(t2.w));
-    v3 e2 = mk3(t0.x, t0.y, t0.z), e1 = mk3(t1.x, t1.y, t1.z), v0 = mk3(t2.x, t2.y, t2.z);
-    bool found = false;
-    v3 r = cross3(d, e2);
-    float a = dot3(e1, r);
-    if (pt_abs(a) > 0.0000001f) {
-        float f = 1.0f / a;
-        v3 s = o - v0;
-        float u = f * dot3(s, r);
-        if (u >= 0.0f && u <= 1.0f) {
-            v3 q = cross3(s, e1);
-            float v = f * dot3(d, q);
-            if (v >= 0.0f && u + v <= 1.0f) {
-                float dist = f * dot3(e2, q);
-                if (dist > 0.0f && dist < hit.t) {
-                    hit.u = u; hit.v = v;
-                    hit.triIndex = attrOffset + pt_asuint(t2.w);
-                    hit.t = dist;
-                    found = true;
-                }
-            }
-        }
-    }
-    return found;
+    return intersect_triangle_rows<true>(t0, t1, t2, attrOffset, o, d, hit);
 }
 
 // tlas.hlsl:129-234 for one instance.  Returns hit.distance < FAR_PLANE; sets stopNow for an occluded shadow ray.
@@ -361,26 +399,7 @@ PT_DEV bool traverse_instance(const DScene& S, v3 wo, v3 wd, uint32_t instIndex,
     uint2 ng = make_uint2(0u, 0x80000000u), tg = make_uint2(0u, 0u);
     while (true) {
         if (ng.y > 0x00FFFFFFu) {
-            uint32_t mask = ng.y;
-            uint32_t childBitIndex = 31u - (uint32_t)__clz((int)mask);
-            uint32_t childNodeBaseIndex = ng.x;
-            ng.y &= ~(1u << childBitIndex);
-            if (ng.y > 0x00FFFFFFu) {
-                stack_push(st, sp, ng);
-                if (sp >= PT_BVH_STACK_SIZE) overflow = true;
-                sp++;
-                if (STATS) cn.maxStack = sp > cn.maxStack ? sp : cn.maxStack;
-            }
-            uint32_t slotIndex = (childBitIndex - 24u) ^ (octinv4 & 255u);
-            uint32_t relativeIndex = (uint32_t)__popc(mask & ~(0xFFFFFFFFu << slotIndex));
-            const uint4* np = S.nodes + (size_t)(nodeOffset + childNodeBaseIndex + relativeIndex) * 5;
-            uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-            uint32_t hitmask = cwbvh_node_hitmask(o, invDir, octinv4, rec.h.t, n0, n1, n2, n3, n4);
-            if (STATS) cn.nodeVisits++;
-            ng.x = n1.x;
-            ng.y = (hitmask & 0xFF000000u) | (n0.w >> 24);
-            tg.x = n1.y;
-            tg.y = hitmask & 0x00FFFFFFu;
+            cwbvh_visit_node<STATS>(S.nodes, nodeOffset, o, invDir, octinv4, rec.h.t, ng, tg, sp, overflow, st, cn);
         } else {
             tg = ng;
             ng = make_uint2(0u, 0u);
@@ -1487,39 +1506,7 @@ PT_DEV bool ray_step(const DScene& S, RayState& r, ST& st, Counters& cn)
     PT_DIAG_WAVE_COUNT(attrFetches);          // wave-level outer iterations
     if (r.ng.y > 0x00FFFFFFu) {
         PT_DIAG_WAVE_COUNT(materialFetches);  // wave-level node-block executions
-        uint32_t mask = r.ng.y;
-        uint32_t childBitIndex = 31u - (uint32_t)__clz((int)mask);
-        uint32_t childNodeBaseIndex = r.ng.x;
-        r.ng.y &= ~(1u << childBitIndex);
-        if (r.ng.y > 0x00FFFFFFu) {
-            stack_push(st, r.sp, r.ng);
-            if (r.sp >= PT_BVH_STACK_SIZE) r.overflow = true;
-            r.sp++;
-            if (STATS) cn.maxStack = r.sp > cn.maxStack ? r.sp : cn.maxStack;
-        }
-        uint32_t slotIndex = (childBitIndex - 24u) ^ (r.octinv4 & 255u);
-        uint32_t relativeIndex = (uint32_t)__popc(mask & ~(0xFFFFFFFFu << slotIndex));
-        uint32_t childNodeIndex = childNodeBaseIndex + relativeIndex;
-        const uint4* np = S.nodes + (size_t)childNodeIndex * 5;
-        uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-        uint32_t hitmask = cwbvh_node_hitmask(r.o, r.invDir, r.octinv4, r.hit.t, n0, n1, n2, n3, n4);
-        if (STATS) cn.nodeVisits++;
-        r.ng.x = n1.x;
-        r.ng.y = (hitmask & 0xFF000000u) | (n0.w >> 24);
-        r.tg.x = n1.y;
-        r.tg.y = hitmask & 0x00FFFFFFu;
-#ifdef PT_PREFETCH_NEXT_NODE
-        // triangles will be tested before the next node is needed: start pulling that node towards the CU now
-        if (r.tg.y != 0u && r.ng.y > 0x00FFFFFFu) {
-            const uint32_t m = r.ng.y;
-            const uint32_t cbi = 31u - (uint32_t)__clz((int)m);
-            const uint32_t sl = (cbi - 24u) ^ (r.octinv4 & 255u);
-            const uint32_t nxt = r.ng.x + (uint32_t)__popc(m & ~(0xFFFFFFFFu << sl));
-            const uint32_t* pp = (const uint32_t*)(S.nodes + (size_t)nxt * 5);
-            uint32_t a = pp[0], b = pp[19];
-            asm volatile("" :: "v"(a), "v"(b));
-        }
-#endif
+        cwbvh_visit_node<STATS>(S.nodes, 0u, r.o, r.invDir, r.octinv4, r.hit.t, r.ng, r.tg, r.sp, r.overflow, st, cn);
     } else {
         r.tg = r.ng;
         r.ng = make_uint2(0u, 0u);
@@ -1543,188 +1530,56 @@ PT_DEV bool ray_step(const DScene& S, RayState& r, ST& st, Counters& cn)
     return false;
 }
 
-// The same traversal in finer steps: one call does EITHER one triangle test (while the current triangle group is
-// not empty) OR pop + node step / group adoption.  Lanes that need a node step no longer wait for the lane with the
-// most triangles in its group; the per-ray operation sequence is unchanged.
+// ray_unistep: the same traversal in finer steps, with ONE memory round trip per wave iteration.  Every lane first decides what it does next
+// -- test the next triangle of its group, or (pop and) visit the next node -- and only computes an ADDRESS; then all lanes
+// request their rows together (3 rows for a triangle, 5 for a node), and after that single wait the node block and the
+// triangle block run one after the other under their lane masks.  With the nested loops of ray_step a wave iteration paid a
+// node round trip and then one more round trip per triangle of its slowest lane (2.1 on average, at 8 % lane utilisation in
+// the triangle block); here a lane with triangles pending simply stays in "triangle mode" for as many iterations as it has
+// triangles while its neighbours keep visiting nodes.  The per-ray sequence of operations is that of traverse_cwbvh.
 template <bool STATS, class ST>
-PT_DEV bool ray_microstep(const DScene& S, RayState& r, ST& st, Counters& cn)
+PT_DEV bool ray_unistep(const DScene& S, RayState& r, ST& st, Counters& cn)
 {
     bool finished = false;
-    if (r.tg.y != 0u) {
-        uint32_t triangleIndex = 31u - (uint32_t)__clz((int)r.tg.y);
-        uint32_t triAddr = r.tg.x + triangleIndex * 3u;
-        intersect_triangle(S.tris, triAddr, r.o, r.d, r.hit);
-        if (STATS) cn.triTests++;
-        r.tg.y -= 1u << triangleIndex;
-        if (r.anyHit && r.hit.t < PT_FAR_PLANE) {
-            finished = true;
-            if (STATS && r.overflow) cn.overflows++;
-        }
+    const bool isTri = r.tg.y != 0u;
+    bool isNode = false;
+    uint32_t triangleIndex = 0u;
+    const uint4* p = S.nodes;
+    if (isTri) {
+        triangleIndex = 31u - (uint32_t)__clz((int)r.tg.y);
+        p = (const uint4*)S.tris + (size_t)(r.tg.x + triangleIndex * 3u);
     } else {
         if (r.ng.y <= 0x00FFFFFFu) {
             if (r.sp > 0u) { --r.sp; r.ng = stack_pop(st, r.sp); }
-            else {
-                finished = true;
-                if (STATS && r.overflow) cn.overflows++;
-            }
+            else finished = true;
         }
         if (!finished) {
             if (r.ng.y > 0x00FFFFFFu) {
-                uint32_t mask = r.ng.y;
-                uint32_t childBitIndex = 31u - (uint32_t)__clz((int)mask);
-                uint32_t childNodeBaseIndex = r.ng.x;
-                r.ng.y &= ~(1u << childBitIndex);
-                if (r.ng.y > 0x00FFFFFFu) {
-                    stack_push(st, r.sp, r.ng);
-                    if (r.sp >= PT_BVH_STACK_SIZE) r.overflow = true;
-                    r.sp++;
-                    if (STATS) cn.maxStack = r.sp > cn.maxStack ? r.sp : cn.maxStack;
-                }
-                uint32_t slotIndex = (childBitIndex - 24u) ^ (r.octinv4 & 255u);
-                uint32_t relativeIndex = (uint32_t)__popc(mask & ~(0xFFFFFFFFu << slotIndex));
-                uint32_t childNodeIndex = childNodeBaseIndex + relativeIndex;
-                const uint4* np = S.nodes + (size_t)childNodeIndex * 5;
-                uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-                uint32_t hitmask = cwbvh_node_hitmask(r.o, r.invDir, r.octinv4, r.hit.t, n0, n1, n2, n3, n4);
-                if (STATS) cn.nodeVisits++;
-                r.ng.x = n1.x;
-                r.ng.y = (hitmask & 0xFF000000u) | (n0.w >> 24);
-                r.tg.x = n1.y;
-                r.tg.y = hitmask & 0x00FFFFFFu;
+                isNode = true;
+                p = S.nodes + (size_t)cwbvh_pick_child<STATS>(r.ng, r.octinv4, r.sp, r.overflow, st, cn) * 5;
             } else {
-                r.tg = r.ng;
+                r.tg = r.ng;                                   // a triangle group came off the stack (util/bvh.hlsl:172-176)
                 r.ng = make_uint2(0u, 0u);
             }
         }
     }
+    uint4 q0 = make_uint4(0u, 0u, 0u, 0u), q1 = q0, q2 = q0, q3 = q0, q4 = q0;
+    if (isTri || isNode) {
+        q0 = p[0]; q1 = p[1]; q2 = p[2];
+        if (isNode) { q3 = p[3]; q4 = p[4]; }
+    }
+    asm volatile("" : "+v"(q0.x), "+v"(q1.x), "+v"(q2.x), "+v"(q3.x), "+v"(q4.x));      // all rows requested before the first use
+    if (isNode) {
+        cwbvh_apply_node<STATS>(r.o, r.invDir, r.octinv4, r.hit.t, q0, q1, q2, q3, q4, r.ng, r.tg, cn);
+    } else if (isTri) {
+        const float4 t0 = make_float4(pt_asfloat(q0.x), pt_asfloat(q0.y), pt_asfloat(q0.z), pt_asfloat(q0.w));
+        const float4 t1 = make_float4(pt_asfloat(q1.x), pt_asfloat(q1.y), pt_asfloat(q1.z), pt_asfloat(q1.w));
+        const float4 t2 = make_float4(pt_asfloat(q2.x), pt_asfloat(q2.y), pt_asfloat(q2.z), pt_asfloat(q2.w));
+        intersect_triangle_rows<false>(t0, t1, t2, 0u, r.o, r.d, r.hit);
+        if (STATS) cn.triTests++;
+        r.tg.y -= 1u << triangleIndex;
+        if (r.anyHit && r.hit.t < PT_FAR_PLANE) finished = true;
+    }
+    if (finished && STATS && r.overflow) cn.overflows++;
     return finished;
-}
-
-// The two halves of ray_microstep as separate phases, so that a wave can decide per iteration WHICH phase to run:
-// triangle tests are short and sparse (measured: the nested triangle loop executed at 8 % lane utilisation and cost
-// more wave-instructions than all node steps together), so the refill trace kernel lets lanes with pending triangles
-// wait until enough of them have accumulated.  A lane's own sequence of operations is unchanged -- it only waits.
-template <bool STATS>
-PT_DEV bool ray_tri_phase(const DScene& S, RayState& r, Counters& cn)          // precondition: r.tg.y != 0
-{
-    uint32_t triangleIndex = 31u - (uint32_t)__clz((int)r.tg.y);
-    uint32_t triAddr = r.tg.x + triangleIndex * 3u;
-    intersect_triangle(S.tris, triAddr, r.o, r.d, r.hit);
-    if (STATS) cn.triTests++;
-    r.tg.y -= 1u << triangleIndex;
-    if (r.anyHit && r.hit.t < PT_FAR_PLANE) {
-        if (STATS && r.overflow) cn.overflows++;
-        return true;
-    }
-    return false;
-}
-
-// Triangle phase for a whole wave: the pending (ray, triangle) pairs of all lanes are dealt out to the lanes, so a leaf with
-// three triangles occupies three lanes and a wave with five such rays runs ONE triangle block instead of three.  Up to three
-// triangles per ray and phase; the rest stays pending.  A worker lane fetches its pair's ray from the owner lane by
-// ds_bpermute, tests the triangle against the ray's current t, and the owner applies its results in the ray's own order
-// (accept iff dist < current t) -- the sequential loop of util/bvh.hlsl:179-190; an any-hit ray stops at, and counts up to,
-// its first accepted triangle.  Every lane of the wave must call this (the shuffles are wave-wide).
-template <bool STATS>
-PT_DEV bool wave_tri_gather(const DScene& S, RayState& r, bool want, volatile uint32_t* list, uint32_t lane, Counters& cn)
-{
-    const unsigned long long ltMask = (1ull << lane) - 1ull;
-    uint32_t bits = want ? r.tg.y : 0u;
-    uint32_t base = 0u, posPack = 0xFFFFFFFFu, taken = 0u;
-#pragma unroll
-    for (int rr = 0; rr < 3; ++rr) {
-        const unsigned long long m = __ballot(bits != 0u);
-        if (m == 0ull || base >= 64u) break;
-        if (bits != 0u) {
-            const uint32_t idx = 31u - (uint32_t)__clz((int)bits);
-            const uint32_t pos = base + (uint32_t)__popcll(m & ltMask);
-            if (pos < 64u) {
-                list[pos] = lane | (idx << 8);
-                taken |= 1u << idx;
-                posPack = (posPack & ~(0xFFu << (8 * rr))) | (pos << (8 * rr));
-            }
-            bits &= ~(1u << idx);
-        }
-        base += (uint32_t)__popcll(m);
-    }
-    const uint32_t nPairs = base < 64u ? base : 64u;
-    __builtin_amdgcn_wave_barrier();
-    const bool worker = lane < nPairs;
-    const uint32_t e = worker ? list[lane] : lane;
-    const int src = (int)(e & 63u);
-    const uint32_t idx = e >> 8;
-    const v3 o = mk3(__shfl(r.o.x, src, 64), __shfl(r.o.y, src, 64), __shfl(r.o.z, src, 64));
-    const v3 d = mk3(__shfl(r.d.x, src, 64), __shfl(r.d.y, src, 64), __shfl(r.d.z, src, 64));
-    const float t0 = __shfl(r.hit.t, src, 64);
-    const uint32_t tgx = (uint32_t)__shfl((int)r.tg.x, src, 64);
-    TraceHit h;
-    h.t = PT_FAR_PLANE * 4.0f; h.u = 0.0f; h.v = 0.0f; h.triIndex = 0u;
-    if (worker) {
-        TraceHit w;
-        w.t = t0; w.u = 0.0f; w.v = 0.0f; w.triIndex = 0u;
-        intersect_triangle(S.tris, tgx + idx * 3u, o, d, w);
-        if (w.t < t0) h = w;                       // accepted against the pre-phase t; otherwise it can never be accepted
-    }
-    __builtin_amdgcn_wave_barrier();
-    // owners walk their results in order
-    bool accepted = false, stop = false;
-    int winner = (int)lane;
-#pragma unroll
-    for (int rr = 0; rr < 3; ++rr) {
-        const uint32_t pos = (posPack >> (8 * rr)) & 255u;
-        const float rt = __shfl(h.t, pos == 255u ? (int)lane : (int)pos, 64);
-        if (pos != 255u && !stop) {
-            if (STATS) cn.triTests++;
-            if (rt < r.hit.t) { r.hit.t = rt; winner = (int)pos; accepted = true; if (r.anyHit) stop = true; }
-        }
-    }
-    const float wu = __shfl(h.u, winner, 64), wv = __shfl(h.v, winner, 64);
-    const uint32_t wi = (uint32_t)__shfl((int)h.triIndex, winner, 64);
-    if (accepted) { r.hit.u = wu; r.hit.v = wv; r.hit.triIndex = wi; }
-    r.tg.y &= ~taken;
-    if (accepted && r.anyHit) {
-        r.tg.y = 0u; r.ng.y = 0u; r.sp = 0u;
-        if (STATS && r.overflow) cn.overflows++;
-        return true;
-    }
-    return false;
-}
-
-template <bool STATS, class ST>
-PT_DEV bool ray_node_phase(const DScene& S, RayState& r, ST& st, Counters& cn)  // precondition: r.tg.y == 0
-{
-    if (r.ng.y <= 0x00FFFFFFu) {
-        if (r.sp > 0u) { --r.sp; r.ng = stack_pop(st, r.sp); }
-        else {
-            if (STATS && r.overflow) cn.overflows++;
-            return true;
-        }
-    }
-    if (r.ng.y > 0x00FFFFFFu) {
-        uint32_t mask = r.ng.y;
-        uint32_t childBitIndex = 31u - (uint32_t)__clz((int)mask);
-        uint32_t childNodeBaseIndex = r.ng.x;
-        r.ng.y &= ~(1u << childBitIndex);
-        if (r.ng.y > 0x00FFFFFFu) {
-            stack_push(st, r.sp, r.ng);
-            if (r.sp >= PT_BVH_STACK_SIZE) r.overflow = true;
-            r.sp++;
-            if (STATS) cn.maxStack = r.sp > cn.maxStack ? r.sp : cn.maxStack;
-        }
-        uint32_t slotIndex = (childBitIndex - 24u) ^ (r.octinv4 & 255u);
-        uint32_t relativeIndex = (uint32_t)__popc(mask & ~(0xFFFFFFFFu << slotIndex));
-        uint32_t childNodeIndex = childNodeBaseIndex + relativeIndex;
-        const uint4* np = S.nodes + (size_t)childNodeIndex * 5;
-        uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-        uint32_t hitmask = cwbvh_node_hitmask(r.o, r.invDir, r.octinv4, r.hit.t, n0, n1, n2, n3, n4);
-        if (STATS) cn.nodeVisits++;
-        r.ng.x = n1.x;
-        r.ng.y = (hitmask & 0xFF000000u) | (n0.w >> 24);
-        r.tg.x = n1.y;
-        r.tg.y = hitmask & 0x00FFFFFFu;
-    } else {
-        r.tg = r.ng;
-        r.ng = make_uint2(0u, 0u);
-    }
-    return false;
 }

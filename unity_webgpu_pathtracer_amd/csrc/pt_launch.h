@@ -21,6 +21,9 @@ hipError_t pt_launch_copy_texture(const float4* dTexture, uint32_t width, uint32
 hipError_t pt_launch_present(const PTPresentParams& Q, const float4* src, float4* dst, hipStream_t stream);
 
 // ---- schedule 1 (wavefront): slot-indexed path state in HBM (see pt_wavefront.hip) ----
+#ifndef PT_WF_LDS_STACK
+#define PT_WF_LDS_STACK 8       // traversal-stack entries per lane kept in LDS by the refill / persistent trace kernels; deeper ones go to stackSpill
+#endif
 struct PTWfBuffers {
     uint32_t* flags;            // [numSlots] packed state word
     uint32_t* rng;              // [numSlots]
@@ -31,6 +34,7 @@ struct PTWfBuffers {
     float4* hit;                // [numSlots] (t, u, v, triIndex bits) written by trace kind 0
     float4* hit2;               // [numSlots] HAS_TLAS only: (world hit position, instance index bits)
     uint8_t* occl;              // [2][numSlots] written by trace kinds 1, 2
+    uint2* stackSpill;          // [numSlots][32 - PT_WF_LDS_STACK]: traversal-stack entries beyond the LDS part (refill / persistent trace kernels)
     uint32_t* aliveFlags;       // [maxIterations]
     uint32_t* chunkHeads;       // [8 shards x 32 words]: work counters of the persistent trace kernel, one 128-B line each
     unsigned long long* statRows;   // [numStatRows][16]

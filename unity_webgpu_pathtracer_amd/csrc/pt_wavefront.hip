@@ -120,9 +120,6 @@ __global__ __launch_bounds__(256) void pt_wf_init(PTFrameParams P, PTTileMap tm,
 #ifndef PT_WF_TRACE_MIN_WAVES
 #define PT_WF_TRACE_MIN_WAVES 8
 #endif
-#ifndef PT_WF_LDS_STACK
-#define PT_WF_LDS_STACK 8
-#endif
 
 template <bool STATS, bool TLAS>
 __global__ __launch_bounds__(256, 4) void pt_wf_trace(DScene S, PTWfBuffers B)
@@ -180,22 +177,30 @@ static_assert(PT_WF_RANGE >= 32u && (PT_WF_RANGE & (PT_WF_RANGE - 1u)) == 0u,
 #define PT_WF_REFILL 16u        // refill when at least this many lanes are idle
 #endif
 #ifndef PT_WF_FLAT
-#define PT_WF_FLAT 0            // 1: ray_microstep (one triangle OR one node step per wave iteration), 0: ray_step
+#define PT_WF_FLAT 0            // 0: ray_step (node visit + all its triangles per wave iteration), 2: ray_unistep (one triangle OR one node visit, one memory round trip)
 #endif
-#if PT_WF_FLAT
-#define PT_WF_STEP ray_microstep
+#if PT_WF_FLAT == 2
+#define PT_WF_STEP ray_unistep
 #else
 #define PT_WF_STEP ray_step
-#endif
-#ifndef PT_WF_TRI_THRESHOLD
-#define PT_WF_TRI_THRESHOLD 0u  // >0: run the triangle phase only when that many lanes have a triangle pending (measured slower: 8: +0 %, 16: -4 %, 32: -12 %); 0 = nested loop
-#endif
-#ifndef PT_WF_GATHER
-#define PT_WF_GATHER 0u         // >0: triangle phases deal (ray, triangle) pairs out to all lanes (wave_tri_gather) once that many lanes have a triangle pending
 #endif
 #ifndef PT_WF_TRACE_BLOCK
 #define PT_WF_TRACE_BLOCK 64u   // threads per workgroup of the refill trace kernel (one wave: a finished wave frees its slot at once)
 #endif
+
+// Result stores of the trace kernels.  The empty asm pins the address arithmetic (and the constant miss record) to the
+// store instead of letting it be hoisted into registers that live across the whole traversal loop (64-VGPR budget).
+PT_DEV void store_miss(const PTWfBuffers& B, uint32_t slot)
+{
+    float far = PT_FAR_PLANE;
+    asm volatile("" : "+v"(far), "+v"(slot));
+    B.hit[slot] = make_float4(far, 0.0f, 0.0f, 0.0f);
+}
+PT_DEV void store_occlusion(const PTWfBuffers& B, uint32_t kind, uint32_t slot, bool occluded)
+{
+    asm volatile("" : "+v"(kind), "+v"(slot));
+    B.occl[(size_t)(kind - 1u) * B.numSlots + slot] = occluded ? 1 : 0;
+}
 
 PT_DEV bool ray_exists(uint32_t f, uint32_t kind)
 {
@@ -216,11 +221,17 @@ __global__ __launch_bounds__(PT_WF_TRACE_BLOCK, PT_WF_TRACE_MIN_WAVES) void pt_w
     const uint32_t nItems = 3u * PT_WF_RANGE;
     const unsigned long long ltMask = (1ull << lane) - 1ull;
     volatile uint32_t* xchg = s_xchg[wave];
+    // the wave's counter row is parked in LDS until the end: kept in a register it is the one value the compiler spilled to
+    // scratch, and ANY scratch costs this kernel its occupancy (see TravStackT)
+    __shared__ uint32_t s_row[PT_WF_TRACE_BLOCK / 64u];
+    if (lane == 0u) s_row[wave] = (B.numSlots >> 6) + gw;
 
     Counters cn = {};
-    TravStackT<PT_WF_LDS_STACK> st;
+    TravStackT<PT_WF_LDS_STACK, true> st;
     st.lds = &s_stack[0][tid];
     st.stride = PT_WF_TRACE_BLOCK;
+    st.gbase = B.stackSpill;
+    st.gidx = gw * 64u + lane;                                        // < numSlots: one row per lane of every trace wave
     RayState rs;
     rs.sp = 0u; rs.anyHit = false; rs.overflow = false;
     bool have = false;
@@ -256,8 +267,8 @@ __global__ __launch_bounds__(PT_WF_TRACE_BLOCK, PT_WF_TRACE_MIN_WAVES) void pt_w
                 if (myKind == 0u) cn.closestRays++; else cn.shadowRays++;
                 if (ray_begin(rs, o, d, myKind != 0u)) {
                     // NaN ray: certain miss
-                    if (myKind == 0u) B.hit[mySlot] = make_float4(PT_FAR_PLANE, 0.0f, 0.0f, 0.0f);
-                    else B.occl[(size_t)(myKind - 1u) * B.numSlots + mySlot] = 0;
+                    if (myKind == 0u) store_miss(B, mySlot);
+                    else store_occlusion(B, myKind, mySlot, false);
                 } else have = true;
             }
             __builtin_amdgcn_wave_barrier();
@@ -268,43 +279,36 @@ __global__ __launch_bounds__(PT_WF_TRACE_BLOCK, PT_WF_TRACE_MIN_WAVES) void pt_w
         // ---- traverse until enough lanes have retired (or, once the range is exhausted, until all have)
         const uint32_t stopAt = cursor < nItems ? PT_WF_REFILL : 64u;
         do {
-#if PT_WF_GATHER > 0
-            const bool wantTri = have && rs.tg.y != 0u;
-            const uint32_t nT = (uint32_t)__popcll(__ballot(wantTri));
-            const uint32_t nN = (uint32_t)__popcll(__ballot(have && !wantTri));
-            bool fin = false;
-            if (nT > 0u && (nT >= PT_WF_GATHER || nN == 0u)) fin = wave_tri_gather<STATS>(S, rs, wantTri, xchg, lane, cn);
-            if (have && !fin && rs.tg.y == 0u) fin = ray_node_phase<STATS>(S, rs, st, cn);
-            if (fin) {
-#elif PT_WF_TRI_THRESHOLD > 0
-            // phase scheduling: the node phase runs whenever a lane wants it; the (short, sparse) triangle phase only when
-            // enough lanes have a triangle pending, or when nobody can do anything else
-            const bool wantTri = have && rs.tg.y != 0u;
-            const uint32_t nT = (uint32_t)__popcll(__ballot(wantTri));
-            const uint32_t nN = (uint32_t)__popcll(__ballot(have && !wantTri));
-            bool fin = false;
-            if (nT >= PT_WF_TRI_THRESHOLD || nN == 0u) {
-                if (wantTri) fin = ray_tri_phase<STATS>(S, rs, cn);
-            }
-            if (have && !fin && rs.tg.y == 0u) fin = ray_node_phase<STATS>(S, rs, st, cn);
-            if (fin) {
-#else
-            if (have) {
-                if (PT_WF_STEP<STATS>(S, rs, st, cn)) {
-#endif
-                    if (myKind == 0u) B.hit[mySlot] = make_float4(rs.hit.t, rs.hit.u, rs.hit.v, pt_asfloat(rs.hit.triIndex));
-                    else B.occl[(size_t)(myKind - 1u) * B.numSlots + mySlot] = rs.hit.t < PT_FAR_PLANE ? 1 : 0;
-                    have = false;
-#if PT_WF_TRI_THRESHOLD > 0 || PT_WF_GATHER > 0
-            }
-#else
+#ifdef PT_TRACE_HIST
+            // diagnostics build: histogram of active lanes per wave iteration, reported through the shading counters
+            // (attrFetches: 1-8 lanes, materialFetches: 9-16, lightFetches: 17-32, texelFetches: 33-48, texDescFetches: 49-64;
+            //  tlasNodeVisits: iterations after the wave's range was exhausted)
+            {
+                const uint32_t nAct = (uint32_t)__popcll(__ballot(have));
+                if (lane == 0u) {
+                    if (nAct <= 8u) cn.attrFetches++; else if (nAct <= 16u) cn.materialFetches++; else if (nAct <= 32u) cn.lightFetches++;
+                    else if (nAct <= 48u) cn.texelFetches++; else cn.texDescFetches++;
+                    if (cursor >= nItems) cn.tlasNodeVisits++;
                 }
             }
 #endif
+            if (have) {
+                // the hit record goes to memory whenever a step improved it, so (u, v, triIndex) need no registers across
+                // iterations (64 VGPRs without a spill = no scratch, see TravStackT); a ray that never hits writes the miss
+                const float tBefore = rs.hit.t;
+                const bool fin = PT_WF_STEP<STATS>(S, rs, st, cn);
+                if (myKind == 0u && rs.hit.t < tBefore) B.hit[mySlot] = make_float4(rs.hit.t, rs.hit.u, rs.hit.v, pt_asfloat(rs.hit.triIndex));
+                if (fin) {
+                    if (myKind == 0u) { if (!(rs.hit.t < PT_FAR_PLANE)) store_miss(B, mySlot); }
+                    else store_occlusion(B, myKind, mySlot, rs.hit.t < PT_FAR_PLANE);
+                    have = false;
+                }
+            }
             nIdle = (uint32_t)__popcll(__ballot(!have));
         } while (nIdle < stopAt);
     }
-    flush_counters<STATS>(cn, B.statRows, (B.numSlots >> 6) + gw, lane);
+    __builtin_amdgcn_wave_barrier();
+    flush_counters<STATS>(cn, B.statRows, ((volatile uint32_t*)s_row)[wave], lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -347,9 +351,11 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_persist
     volatile uint32_t* xchg = s_xchg;
 
     Counters cn = {};
-    TravStackT<PT_WF_LDS_STACK> st;
+    TravStackT<PT_WF_LDS_STACK, true> st;
     st.lds = &s_stack[0][lane];
     st.stride = 64u;
+    st.gbase = B.stackSpill;
+    st.gidx = blockIdx.x * 64u + lane;                                // grid <= numSlots / 64 waves
     RayState rs;
     rs.sp = 0u; rs.anyHit = false; rs.overflow = false;
     bool have = false;
@@ -391,8 +397,8 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_persist
                 else { o = xyz(B.neeO[mySlot]); d = xyz(myKind == 1u ? B.envD[mySlot] : B.lightD[mySlot]); }
                 if (myKind == 0u) cn.closestRays++; else cn.shadowRays++;
                 if (ray_begin(rs, o, d, myKind != 0u)) {
-                    if (myKind == 0u) B.hit[mySlot] = make_float4(PT_FAR_PLANE, 0.0f, 0.0f, 0.0f);
-                    else B.occl[(size_t)(myKind - 1u) * B.numSlots + mySlot] = 0;
+                    if (myKind == 0u) store_miss(B, mySlot);
+                    else store_occlusion(B, myKind, mySlot, false);
                 } else have = true;
             }
             __builtin_amdgcn_wave_barrier();
@@ -403,9 +409,12 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_persist
         const uint32_t stopAt = more ? PT_WF_REFILL : 64u;
         do {
             if (have) {
-                if (PT_WF_STEP<STATS>(S, rs, st, cn)) {
-                    if (myKind == 0u) B.hit[mySlot] = make_float4(rs.hit.t, rs.hit.u, rs.hit.v, pt_asfloat(rs.hit.triIndex));
-                    else B.occl[(size_t)(myKind - 1u) * B.numSlots + mySlot] = rs.hit.t < PT_FAR_PLANE ? 1 : 0;
+                const float tBefore = rs.hit.t;
+                const bool fin = PT_WF_STEP<STATS>(S, rs, st, cn);
+                if (myKind == 0u && rs.hit.t < tBefore) B.hit[mySlot] = make_float4(rs.hit.t, rs.hit.u, rs.hit.v, pt_asfloat(rs.hit.triIndex));
+                if (fin) {
+                    if (myKind == 0u) { if (!(rs.hit.t < PT_FAR_PLANE)) store_miss(B, mySlot); }
+                    else store_occlusion(B, myKind, mySlot, rs.hit.t < PT_FAR_PLANE);
                     have = false;
                 }
             }
