@@ -29,6 +29,11 @@ import zlib
 
 import numpy as np
 
+# consecutive passes overlap on PT_WF_SETS streams; the HIP runtime maps streams onto this many hardware queues (default 4)
+# and streams that share a queue serialise.  Must be set before the first HIP call (the plugin sets the same default when
+# it is loaded first; here torch initialises HIP before the plugin is loaded).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -111,6 +116,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL (default); gloo only to rehearse N>1 on a one-GPU box")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--force-dist", action="store_true", help="rehearsal: run the N>1 code path (process group, per-frame reduce) even with one rank")
+    ap.add_argument("--wf-iterations", type=int, default=0, help="wavefront trace+shade iterations per pass before the cleanup kernel (0 = automatic; any value gives the same frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alg-replay", action="store_true", help="profiling runs: skip the untimed full-counter replay (roofline.achieved is then null)")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads reported under 'other_workloads'")
@@ -148,6 +154,8 @@ def main():
         pt = PathTracer(scene, device=local_rank, width=W, height=H, samplesPerPass=SPP, maxRayBounces=args.bounces,
                         rank=rank, world_size=world)
         pt.set_schedule(args.schedule)
+        if args.wf_iterations:
+            pt.set_wavefront_iterations(args.wf_iterations)
         frames = [torch.zeros((H, W, 4), dtype=torch.float32, device=device) for _ in range(2)]
         # N > 1: the rank's two frames keep its own tiles (they are the next pass's AccumulatedOutput); the frame is
         # assembled on rank 0 in a third buffer, so nothing depends on what a reduce leaves in non-root buffers

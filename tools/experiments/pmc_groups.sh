@@ -4,7 +4,7 @@
 TAG=$1
 [ -n "$2" ] && export PT_PLUGIN=$(realpath $2)
 export TMPDIR=/tmp
-CMD="python3 bench.py --steps 4 --warmup 1 --no-extra --no-cpu-baseline --no-alg-replay"
+CMD="python3 bench.py --steps 4 --warmup 1 --no-extra --no-cpu-baseline --no-alg-replay $BENCH_EXTRA"
 i=0
 while read -r GROUP; do
   [ -z "$GROUP" ] && continue
@@ -18,4 +18,5 @@ TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum
 TCP_TOTAL_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum
 TD_TD_BUSY_sum TD_TC_STALL_sum
 GRBM_GUI_ACTIVE
+SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_BRANCH
 GROUPS

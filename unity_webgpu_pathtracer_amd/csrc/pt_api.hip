@@ -14,6 +14,13 @@
 
 namespace {
 
+// Consecutive passes run on PT_WF_SETS streams so that one pass's launch tails are filled by its neighbours' kernels.  The
+// HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, one of them the context stream's):
+// streams that share a queue serialise.  Ask for 8 unless the host has already chosen; this runs when the library is loaded,
+// i.e. before the first HIP call of a host that loads the plugin first (a host that has initialised HIP already keeps its
+// own setting -- bench.py therefore sets the variable itself before importing torch).
+__attribute__((constructor)) void pt_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 thread_local std::string g_lastError;
 
 int fail(int code, const std::string& msg)
@@ -111,8 +118,9 @@ int ensure_wavefront(PTContext* c, PTContext::WfSet& set, uint32_t numSlots, uin
     const uint32_t numRows = 4u * (numSlots >> 6);
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t spillBytes = n * (size_t)(PT_BVH_STACK_SIZE - PT_WF_LDS_STACK) * sizeof(uint2);
+    const size_t suspBytes = (n >> 6) * (size_t)PT_WF_SUSPEND_MAX * 6 * sizeof(uint4);
     size_t total = align(n * 4) * 2 + align(n * 16) * 13 + align(n * 2) + align((size_t)maxIterations * 4) +
-                   align((size_t)numRows * 16 * 8) + align(8 * 32 * 4) + align(spillBytes);
+                   align((size_t)numRows * 16 * 8) + align(8 * 32 * 4) + align(spillBytes) + align(suspBytes) + align((n >> 6) * 4);
     if (set.arena && set.arenaBytes < total) { hipFree(set.arena); set.arena = nullptr; set.arenaBytes = 0; }
     if (!set.arena) {
         HIP_TRY(hipMalloc(&set.arena, total));
@@ -130,6 +138,8 @@ int ensure_wavefront(PTContext* c, PTContext::WfSet& set, uint32_t numSlots, uin
     B.statRows = (unsigned long long*)carve((size_t)numRows * 16 * 8);
     B.chunkHeads = (uint32_t*)carve(8 * 32 * 4);
     B.stackSpill = (uint2*)carve(spillBytes);
+    B.susp = (uint4*)carve(suspBytes);
+    B.suspCount = (uint32_t*)carve((n >> 6) * 4);
     {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, c->device));

@@ -125,6 +125,9 @@ PT_DEV float rnd(uint32_t& s) { return pt_random_float(&s); }
 // makes the dispatcher allocate a scratch wave slot per wave: for the refill trace kernel that allocation, not registers
 // or LDS, was what limited the waves in flight (SPI_RA_TMP_STALL_CSN 1.7e9 vs SPI_RA_WAVE_SIMD_FULL_CSN 1.9e7 per five
 // passes; removing the 192-byte array: +8 % end to end).  The slab is touched only by rays deeper than LDSN entries.
+typedef const volatile __attribute__((address_space(3))) uint32_t* pt_lds_word;    // an LDS address (32 bits, no flat pointer)
+#define PT_LDS_WORD(var) ((pt_lds_word)(&(var)))
+
 template <int LDSN, bool GSPILL = false>
 struct TravStackT {
     static constexpr uint32_t kLds = LDSN;
@@ -133,20 +136,25 @@ struct TravStackT {
     uint32_t stride;
     uint2 spill[GSPILL ? 1 : PT_BVH_STACK_SIZE - LDSN];
     uint2* gbase;               // GSPILL: slab base (wave-uniform)
-    uint32_t gidx;              // GSPILL: this lane's row in the slab
+    pt_lds_word gwave;          // GSPILL: LDS word holding this wave's index; the lane's slab row is *gwave * 64 + lane
 };
 typedef TravStackT<PT_LDS_STACK> TravStack;
 
-// The slab address is formed where it is used (the empty asm keeps the compiler from hoisting the 64-bit address out of the
-// traversal loop, where it would occupy -- and at 64 VGPRs spill -- two registers for a path that almost never runs).
-PT_DEV size_t spill_row(uint32_t gidx) { asm volatile("" : "+v"(gidx)); return (size_t)gidx; }
+// The slab row is formed where it is used, from an LDS word and the lane id: nothing about the (almost never taken) slab
+// path lives in a register across the traversal loop, where at 64 VGPRs it would be spilled -- to scratch.
+PT_DEV size_t spill_row(pt_lds_word gwave)
+{
+    uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(lane));
+    return (size_t)(*gwave * 64u + lane);
+}
 
 template <class ST>
 PT_DEV void stack_push(ST& st, uint32_t sp, uint2 v)
 {
     if (sp < ST::kLds) st.lds[sp * st.stride] = v;
     else if (sp < PT_BVH_STACK_SIZE) {
-        if (ST::kGlobalSpill) st.gbase[spill_row(st.gidx) * (PT_BVH_STACK_SIZE - ST::kLds) + (sp - ST::kLds)] = v;
+        if (ST::kGlobalSpill) st.gbase[spill_row(st.gwave) * (PT_BVH_STACK_SIZE - ST::kLds) + (sp - ST::kLds)] = v;
         else st.spill[ST::kGlobalSpill ? 0u : sp - ST::kLds] = v;
     }
 }
@@ -155,7 +163,7 @@ PT_DEV uint2 stack_pop(ST& st, uint32_t sp)
 {
     if (sp < ST::kLds) return st.lds[sp * st.stride];
     if (sp < PT_BVH_STACK_SIZE) {
-        if (ST::kGlobalSpill) return st.gbase[spill_row(st.gidx) * (PT_BVH_STACK_SIZE - ST::kLds) + (sp - ST::kLds)];
+        if (ST::kGlobalSpill) return st.gbase[spill_row(st.gwave) * (PT_BVH_STACK_SIZE - ST::kLds) + (sp - ST::kLds)];
         return st.spill[ST::kGlobalSpill ? 0u : sp - ST::kLds];
     }
     return make_uint2(0u, 0u);

@@ -35,6 +35,8 @@ struct PTWfBuffers {
     float4* hit2;               // [numSlots] HAS_TLAS only: (world hit position, instance index bits)
     uint8_t* occl;              // [2][numSlots] written by trace kinds 1, 2
     uint2* stackSpill;          // [numSlots][32 - PT_WF_LDS_STACK]: traversal-stack entries beyond the LDS part (refill / persistent trace kernels)
+    uint4* susp;                // [numSlots / 64][PT_WF_SUSPEND_MAX][6]: suspended rays of the refill trace kernel (pt_wavefront.hip)
+    uint32_t* suspCount;        // [numSlots / 64]
     uint32_t* aliveFlags;       // [maxIterations]
     uint32_t* chunkHeads;       // [8 shards x 32 words]: work counters of the persistent trace kernel, one 128-B line each
     unsigned long long* statRows;   // [numStatRows][16]
@@ -47,7 +49,7 @@ hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const fl
                                const PTTileMap& tm, const PTWfBuffers& B, unsigned long long* gstats, bool fullStats,
                                hipStream_t stream, hipEvent_t orderAfter, bool zeroOutputFirst,
                                uint32_t* launchesOut, int traceVariant, uint32_t iterationsOverride);
+#define PT_WF_SUSPEND_MAX 32u   // record slots per trace wave (PT_WF_SUSPEND <= this)
 #ifndef PT_WF_SETS
-#define PT_WF_SETS 3
+#define PT_WF_SETS 6             // path-state sets = passes that can be in flight at once, each on its own stream (3 -> 6 sets with 8 hardware queues: +12 %)
 #endif
-//      // path-state sets = passes that can be in flight at once

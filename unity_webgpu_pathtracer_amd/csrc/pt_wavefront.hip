@@ -171,8 +171,8 @@ __global__ __launch_bounds__(256, 4) void pt_wf_trace(DScene S, PTWfBuffers B)
 #ifndef PT_WF_RANGE
 #define PT_WF_RANGE 64u         // slots per wave (power of two); small ranges balance load across CUs (measured 64 > 128 > 256)
 #endif
-static_assert(PT_WF_RANGE >= 32u && (PT_WF_RANGE & (PT_WF_RANGE - 1u)) == 0u,
-              "one counter row per trace wave: pt_api.hip sizes statRows for 4 x numSlots/64 rows, of which the trace kernels use rows numSlots/64 .. numSlots/64 + numSlots/PT_WF_RANGE");
+static_assert(PT_WF_RANGE >= 64u && (PT_WF_RANGE & (PT_WF_RANGE - 1u)) == 0u,
+              "one counter row per trace wave: pt_api.hip sizes statRows for 4 x numSlots/64 rows; the main trace launch uses rows numSlots/64 + wave, the tail launch rows 2 x numSlots/64 + wave");
 #ifndef PT_WF_REFILL
 #define PT_WF_REFILL 16u        // refill when at least this many lanes are idle
 #endif
@@ -183,9 +183,6 @@ static_assert(PT_WF_RANGE >= 32u && (PT_WF_RANGE & (PT_WF_RANGE - 1u)) == 0u,
 #define PT_WF_STEP ray_unistep
 #else
 #define PT_WF_STEP ray_step
-#endif
-#ifndef PT_WF_TRACE_BLOCK
-#define PT_WF_TRACE_BLOCK 64u   // threads per workgroup of the refill trace kernel (one wave: a finished wave frees its slot at once)
 #endif
 
 // Result stores of the trace kernels.  The empty asm pins the address arithmetic (and the constant miss record) to the
@@ -209,86 +206,166 @@ PT_DEV bool ray_exists(uint32_t f, uint32_t kind)
     return fl_pending(f) && fl_light(f) != 0u;
 }
 
-template <bool STATS>
-__global__ __launch_bounds__(PT_WF_TRACE_BLOCK, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(DScene S, PTWfBuffers B)
+// ---- suspension (PT_WF_SUSPEND > 0) -----------------------------------------------------------------------------------
+// A launch only holds 5-6 rays per lane of the chip, and ray lengths spread over an order of magnitude, so a wave spends
+// most of its iterations DRAINING: measured on the Sponza-class pass, 54 % of all wave iterations ran after the wave's
+// range was exhausted and 32 % with <= 16 active lanes, each costing the same ~450 VALU instructions and memory round
+// trips as a full one.  So a wave whose range is exhausted stops as soon as PT_WF_SUSPEND or fewer rays are left: it
+// writes those rays' traversal state (node group, triangle group, stack, t: 96 bytes) to a record array and exits, and a
+// TAIL launch of the same kernel packs the records of PT_WF_TAIL_GROUP consecutive waves into full waves and resumes
+// them.  A ray resumes exactly where it stopped, so results and counters are unchanged; late, sparse iterations (a
+// handful of rays per 64-slot range) become a cheap scan + an 8:1 compacted tail.
+#ifndef PT_WF_SUSPEND
+#define PT_WF_SUSPEND 16u       // 0 = off
+#endif
+#ifndef PT_WF_TAIL_GROUP
+#define PT_WF_TAIL_GROUP 8u     // source waves per tail wave
+#endif
+#define PT_WF_SUSP_ROWS 6u      // uint4 rows per record
+
+template <class ST>
+PT_DEV void suspend_ray(const PTWfBuffers& B, uint32_t rec, uint32_t slot, uint32_t kind, const RayState& r, ST& st)
 {
-    __shared__ uint2 s_stack[PT_WF_LDS_STACK][PT_WF_TRACE_BLOCK];
-    __shared__ uint32_t s_xchg[PT_WF_TRACE_BLOCK / 64u][64];
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-    const uint32_t gw = blockIdx.x * (PT_WF_TRACE_BLOCK / 64u) + wave;
-    const uint32_t slotBase = gw * PT_WF_RANGE;
-    if (slotBase >= B.numSlots) return;                              // wave-uniform
-    const uint32_t nItems = 3u * PT_WF_RANGE;
-    const unsigned long long ltMask = (1ull << lane) - 1ull;
-    volatile uint32_t* xchg = s_xchg[wave];
+    uint4* p = B.susp + (size_t)rec * PT_WF_SUSP_ROWS;
+    p[0] = make_uint4(slot | (kind << 30), r.sp | (r.overflow ? 0x100u : 0u), r.ng.x, r.ng.y);
+    p[1] = make_uint4(r.tg.x, r.tg.y, pt_asuint(r.hit.t), 0u);
+#pragma unroll
+    for (uint32_t e = 0; e < 4u; ++e) {
+        const uint2 x = st.lds[(2u * e) * st.stride], y = st.lds[(2u * e + 1u) * st.stride];
+        p[2u + e] = make_uint4(x.x, x.y, y.x, y.y);
+    }
+}
+static_assert(PT_WF_LDS_STACK == 8, "a suspension record holds the eight LDS stack entries");
+
+template <bool STATS, bool TAIL>
+__global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(DScene S, PTWfBuffers B)
+{
+    __shared__ uint2 s_stack[PT_WF_LDS_STACK][64];
+    __shared__ uint32_t s_xchg[TAIL ? PT_WF_TAIL_GROUP * (PT_WF_SUSPEND ? PT_WF_SUSPEND : 1u) : 64u];
     // the wave's counter row is parked in LDS until the end: kept in a register it is the one value the compiler spilled to
     // scratch, and ANY scratch costs this kernel its occupancy (see TravStackT)
-    __shared__ uint32_t s_row[PT_WF_TRACE_BLOCK / 64u];
-    if (lane == 0u) s_row[wave] = (B.numSlots >> 6) + gw;
+    __shared__ uint32_t s_gw;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t gw = blockIdx.x;
+    const uint32_t numWaves = (B.numSlots + PT_WF_RANGE - 1u) / PT_WF_RANGE;
+    const uint32_t slotBase = gw * PT_WF_RANGE;
+    const unsigned long long ltMask = (1ull << lane) - 1ull;
+    volatile uint32_t* xchg = s_xchg;
+    if (lane == 0u) s_gw = gw;
+
+    // candidates: the main launch scans the flag words of its slot range, kind-major; the tail launch walks the records that
+    // its PT_WF_TAIL_GROUP source waves left behind (their indices, packed, in s_xchg)
+    uint32_t nItems = 3u * PT_WF_RANGE;
+    if (TAIL) {
+        const uint32_t s0 = gw * PT_WF_TAIL_GROUP;
+        uint32_t c = 0u;
+        if (lane < PT_WF_TAIL_GROUP && s0 + lane < numWaves) c = B.suspCount[s0 + lane];
+        uint32_t incl = c;                                            // inclusive prefix over lanes 0..PT_WF_TAIL_GROUP-1
+#pragma unroll
+        for (uint32_t off = 1u; off < PT_WF_TAIL_GROUP; off <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64); if (lane >= off) incl += o; }
+        nItems = (uint32_t)__shfl((int)incl, (int)PT_WF_TAIL_GROUP - 1, 64);
+        constexpr uint32_t kT = PT_WF_SUSPEND ? PT_WF_SUSPEND : 1u;
+#pragma unroll
+        for (uint32_t r = 0; r < (PT_WF_TAIL_GROUP * kT + 63u) / 64u; ++r) {
+            const uint32_t q = r * 64u + lane, i = q / kT, k = q % kT;
+            const uint32_t ci = (uint32_t)__shfl((int)c, (int)(i & 63u), 64), pi = (uint32_t)__shfl((int)(incl - c), (int)(i & 63u), 64);
+            if (i < PT_WF_TAIL_GROUP && k < ci) xchg[pi + k] = (s0 + i) * kT + k;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (nItems == 0u) return;                                     // wave-uniform; nothing was counted
+    }
 
     Counters cn = {};
     TravStackT<PT_WF_LDS_STACK, true> st;
-    st.lds = &s_stack[0][tid];
-    st.stride = PT_WF_TRACE_BLOCK;
+    st.lds = &s_stack[0][lane];
+    st.stride = 64u;
     st.gbase = B.stackSpill;
-    st.gidx = gw * 64u + lane;                                        // < numSlots: one row per lane of every trace wave
+    st.gwave = PT_LDS_WORD(s_gw);                                                 // slab row = wave * 64 + lane < numSlots
     RayState rs;
     rs.sp = 0u; rs.anyHit = false; rs.overflow = false;
     bool have = false;
     uint32_t mySlot = 0u, myKind = 0u;
-    uint32_t cursor = 0u;
+    uint32_t cursor = 0u, nSuspended = 0u;
 
     while (true) {
         uint32_t nIdle = (uint32_t)__popcll(__ballot(!have));
-        // ---- refill: compact the next existing rays of this wave's range into the idle lanes
+        // ---- refill: compact the next candidates into the idle lanes
         while (cursor < nItems && (nIdle >= PT_WF_REFILL || nIdle == 64u)) {
             const unsigned long long idle = __ballot(!have);
-            const uint32_t item = cursor + lane;
-            const uint32_t kind = item / PT_WF_RANGE;
-            const uint32_t slot = slotBase + (item & (PT_WF_RANGE - 1u));
-            bool valid = item < nItems && slot < B.numSlots;
-            if (valid) valid = ray_exists(B.flags[slot], kind);
-            const unsigned long long V = __ballot(valid);
-            const uint32_t nV = (uint32_t)__popcll(V);
-            const uint32_t take = nIdle < nV ? nIdle : nV;
-            const uint32_t rankV = (uint32_t)__popcll(V & ltMask);
-            uint32_t consumed = 64u;
-            if (take < nV) consumed = (uint32_t)__ffsll((long long)__ballot(valid && rankV == take)) - 1u;   // first ray NOT taken
-            if (valid && rankV < take) xchg[rankV] = item;
-            __builtin_amdgcn_wave_barrier();
             const uint32_t rankI = (uint32_t)__popcll(idle & ltMask);
-            if (!have && rankI < take) {
-                const uint32_t it = xchg[rankI];
-                myKind = it / PT_WF_RANGE;
-                mySlot = slotBase + (it & (PT_WF_RANGE - 1u));
-                v3 o, d;
-                if (myKind == 0u) { o = xyz(B.ro[mySlot]); d = xyz(B.rd[mySlot]); }
-                else { o = xyz(B.neeO[mySlot]); d = xyz(myKind == 1u ? B.envD[mySlot] : B.lightD[mySlot]); }
-                if (myKind == 0u) cn.closestRays++; else cn.shadowRays++;
-                if (ray_begin(rs, o, d, myKind != 0u)) {
-                    // NaN ray: certain miss
-                    if (myKind == 0u) store_miss(B, mySlot);
-                    else store_occlusion(B, myKind, mySlot, false);
-                } else have = true;
+            if (!TAIL) {
+                const uint32_t item = cursor + lane;
+                const uint32_t kind = item / PT_WF_RANGE;
+                const uint32_t slot = slotBase + (item & (PT_WF_RANGE - 1u));
+                bool valid = item < nItems && slot < B.numSlots;
+                if (valid) valid = ray_exists(B.flags[slot], kind);
+                const unsigned long long V = __ballot(valid);
+                const uint32_t nV = (uint32_t)__popcll(V);
+                const uint32_t take = nIdle < nV ? nIdle : nV;
+                const uint32_t rankV = (uint32_t)__popcll(V & ltMask);
+                uint32_t consumed = 64u;
+                if (take < nV) consumed = (uint32_t)__ffsll((long long)__ballot(valid && rankV == take)) - 1u;   // first ray NOT taken
+                if (valid && rankV < take) xchg[rankV] = item;
+                __builtin_amdgcn_wave_barrier();
+                if (!have && rankI < take) {
+                    const uint32_t it = xchg[rankI];
+                    myKind = it / PT_WF_RANGE;
+                    mySlot = slotBase + (it & (PT_WF_RANGE - 1u));
+                    v3 o, d;
+                    if (myKind == 0u) { o = xyz(B.ro[mySlot]); d = xyz(B.rd[mySlot]); }
+                    else { o = xyz(B.neeO[mySlot]); d = xyz(myKind == 1u ? B.envD[mySlot] : B.lightD[mySlot]); }
+                    if (myKind == 0u) cn.closestRays++; else cn.shadowRays++;
+                    if (ray_begin(rs, o, d, myKind != 0u)) {
+                        // NaN ray: certain miss
+                        if (myKind == 0u) store_miss(B, mySlot);
+                        else store_occlusion(B, myKind, mySlot, false);
+                    } else have = true;
+                }
+                __builtin_amdgcn_wave_barrier();
+                cursor += consumed;
+            } else {
+                const uint32_t left = nItems - cursor;
+                const uint32_t take = nIdle < left ? nIdle : left;
+                if (!have && rankI < take) {
+                    const uint4* p = B.susp + (size_t)xchg[cursor + rankI] * PT_WF_SUSP_ROWS;
+                    const uint4 a = p[0], b = p[1], e0 = p[2], e1 = p[3], e2 = p[4], e3 = p[5];
+                    mySlot = a.x & 0x3FFFFFFFu;
+                    myKind = a.x >> 30;
+                    v3 o, d;
+                    if (myKind == 0u) { o = xyz(B.ro[mySlot]); d = xyz(B.rd[mySlot]); }
+                    else { o = xyz(B.neeO[mySlot]); d = xyz(myKind == 1u ? B.envD[mySlot] : B.lightD[mySlot]); }
+                    ray_begin(rs, o, d, myKind != 0u);                // same invDir / octinv4 as when the ray started
+                    rs.sp = a.y & 0xFFu;
+                    rs.overflow = (a.y & 0x100u) != 0u;
+                    rs.ng = make_uint2(a.z, a.w);
+                    rs.tg = make_uint2(b.x, b.y);
+                    rs.hit.t = pt_asfloat(b.z);
+                    st.lds[0u * 64u] = make_uint2(e0.x, e0.y); st.lds[1u * 64u] = make_uint2(e0.z, e0.w);
+                    st.lds[2u * 64u] = make_uint2(e1.x, e1.y); st.lds[3u * 64u] = make_uint2(e1.z, e1.w);
+                    st.lds[4u * 64u] = make_uint2(e2.x, e2.y); st.lds[5u * 64u] = make_uint2(e2.z, e2.w);
+                    st.lds[6u * 64u] = make_uint2(e3.x, e3.y); st.lds[7u * 64u] = make_uint2(e3.z, e3.w);
+                    have = true;
+                }
+                cursor += take;
             }
-            __builtin_amdgcn_wave_barrier();
-            cursor += consumed;
             nIdle = (uint32_t)__popcll(__ballot(!have));
         }
-        if (nIdle == 64u) break;                                      // range exhausted and nothing in flight
-        // ---- traverse until enough lanes have retired (or, once the range is exhausted, until all have)
-        const uint32_t stopAt = cursor < nItems ? PT_WF_REFILL : 64u;
-        do {
+        if (nIdle == 64u) break;                                      // candidates exhausted and nothing in flight
+        // ---- traverse until enough lanes have retired; once the candidates are exhausted, until PT_WF_SUSPEND or fewer rays
+        //      are left (main launch) or all have finished (tail launch)
+        const bool exhausted = cursor >= nItems;
+        const uint32_t stopAt = !exhausted ? PT_WF_REFILL : ((!TAIL && PT_WF_SUSPEND > 0u) ? 64u - PT_WF_SUSPEND : 64u);
+        while (nIdle < stopAt) {
 #ifdef PT_TRACE_HIST
             // diagnostics build: histogram of active lanes per wave iteration, reported through the shading counters
             // (attrFetches: 1-8 lanes, materialFetches: 9-16, lightFetches: 17-32, texelFetches: 33-48, texDescFetches: 49-64;
-            //  tlasNodeVisits: iterations after the wave's range was exhausted)
+            //  tlasNodeVisits: iterations after the wave's candidates were exhausted)
             {
                 const uint32_t nAct = (uint32_t)__popcll(__ballot(have));
                 if (lane == 0u) {
                     if (nAct <= 8u) cn.attrFetches++; else if (nAct <= 16u) cn.materialFetches++; else if (nAct <= 32u) cn.lightFetches++;
                     else if (nAct <= 48u) cn.texelFetches++; else cn.texDescFetches++;
-                    if (cursor >= nItems) cn.tlasNodeVisits++;
+                    if (exhausted) cn.tlasNodeVisits++;
                 }
             }
 #endif
@@ -305,10 +382,33 @@ __global__ __launch_bounds__(PT_WF_TRACE_BLOCK, PT_WF_TRACE_MIN_WAVES) void pt_w
                 }
             }
             nIdle = (uint32_t)__popcll(__ballot(!have));
-        } while (nIdle < stopAt);
+        }
+        if (!TAIL && PT_WF_SUSPEND > 0u && exhausted && nIdle < 64u) {
+            // a ray whose stack reaches into the HBM slab stays (the record only holds the LDS entries): finish those first
+            if (__ballot(have && rs.sp > PT_WF_LDS_STACK) != 0ull) {
+                while (__ballot(have && rs.sp > PT_WF_LDS_STACK) != 0ull) {
+                    if (have) {
+                        const float tBefore = rs.hit.t;
+                        const bool fin = PT_WF_STEP<STATS>(S, rs, st, cn);
+                        if (myKind == 0u && rs.hit.t < tBefore) B.hit[mySlot] = make_float4(rs.hit.t, rs.hit.u, rs.hit.v, pt_asfloat(rs.hit.triIndex));
+                        if (fin) {
+                            if (myKind == 0u) { if (!(rs.hit.t < PT_FAR_PLANE)) store_miss(B, mySlot); }
+                            else store_occlusion(B, myKind, mySlot, rs.hit.t < PT_FAR_PLANE);
+                            have = false;
+                        }
+                    }
+                }
+            }
+            const unsigned long long act = __ballot(have);
+            if (have) suspend_ray(B, *PT_LDS_WORD(s_gw) * PT_WF_SUSPEND + (uint32_t)__popcll(act & ltMask), mySlot, myKind, rs, st);
+            have = false;
+            nSuspended = (uint32_t)__popcll(act);
+            break;
+        }
     }
+    if (!TAIL && PT_WF_SUSPEND > 0u && lane == 0u) B.suspCount[*PT_LDS_WORD(s_gw)] = nSuspended;     // every main wave reports, zero included
     __builtin_amdgcn_wave_barrier();
-    flush_counters<STATS>(cn, B.statRows, ((volatile uint32_t*)s_row)[wave], lane);
+    flush_counters<STATS>(cn, B.statRows, (TAIL ? 2u : 1u) * (B.numSlots >> 6) + *PT_LDS_WORD(s_gw), lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -355,7 +455,9 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_persist
     st.lds = &s_stack[0][lane];
     st.stride = 64u;
     st.gbase = B.stackSpill;
-    st.gidx = blockIdx.x * 64u + lane;                                // grid <= numSlots / 64 waves
+    __shared__ uint32_t s_gw;
+    if (lane == 0u) s_gw = blockIdx.x;
+    st.gwave = PT_LDS_WORD(s_gw);                                                 // grid <= numSlots / 64 waves
     RayState rs;
     rs.sp = 0u; rs.anyHit = false; rs.overflow = false;
     bool have = false;
@@ -644,8 +746,7 @@ hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const fl
     // a sample needs at most (bounces + 1) closest-hit iterations + 1 to apply its last NEE; alpha-skips beyond that go to cleanup
     uint32_t iterations = iterationsOverride ? iterationsOverride : spp * (bounces + 2u) + 4u;
     if (iterations > B.maxIterations) iterations = B.maxIterations;
-    const uint32_t traceWavesPerBlock = PT_WF_TRACE_BLOCK / 64u;
-    const uint32_t refillBlocks = (B.numSlots + PT_WF_RANGE * traceWavesPerBlock - 1u) / (PT_WF_RANGE * traceWavesPerBlock);
+    const uint32_t refillBlocks = (B.numSlots + PT_WF_RANGE - 1u) / PT_WF_RANGE;                 // one wave per workgroup
     for (uint32_t it = 0; it < iterations; ++it) {
         if (traceVariant == 0) {
             const uint32_t numChunks = (B.numSlots + PT_WF_CHUNK - 1u) / PT_WF_CHUNK;
@@ -654,8 +755,14 @@ hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const fl
             if (fullStats) hipLaunchKernelGGL(pt_wf_trace_persist<true>, dim3(waves), dim3(64), 0, stream, S, B);
             else hipLaunchKernelGGL(pt_wf_trace_persist<false>, dim3(waves), dim3(64), 0, stream, S, B);
         } else if (traceVariant == 2) {
-            if (fullStats) hipLaunchKernelGGL(pt_wf_trace_refill<true>, dim3(refillBlocks), dim3(PT_WF_TRACE_BLOCK), 0, stream, S, B);
-            else hipLaunchKernelGGL(pt_wf_trace_refill<false>, dim3(refillBlocks), dim3(PT_WF_TRACE_BLOCK), 0, stream, S, B);
+            if (fullStats) hipLaunchKernelGGL((pt_wf_trace_refill<true, false>), dim3(refillBlocks), dim3(64), 0, stream, S, B);
+            else hipLaunchKernelGGL((pt_wf_trace_refill<false, false>), dim3(refillBlocks), dim3(64), 0, stream, S, B);
+            if (PT_WF_SUSPEND > 0u) {
+                const uint32_t tailBlocks = (refillBlocks + PT_WF_TAIL_GROUP - 1u) / PT_WF_TAIL_GROUP;
+                if (fullStats) hipLaunchKernelGGL((pt_wf_trace_refill<true, true>), dim3(tailBlocks), dim3(64), 0, stream, S, B);
+                else hipLaunchKernelGGL((pt_wf_trace_refill<false, true>), dim3(tailBlocks), dim3(64), 0, stream, S, B);
+                launches++;
+            }
         } else if (tlas) {
             if (fullStats) hipLaunchKernelGGL((pt_wf_trace<true, true>), dim3(nb * 3u), dim3(256), 0, stream, S, B);
             else hipLaunchKernelGGL((pt_wf_trace<false, true>), dim3(nb * 3u), dim3(256), 0, stream, S, B);
