@@ -5,7 +5,11 @@
  *   PathTracer.cs:226-272 per-frame uniforms -> dispatch -> _currentSample += spp -> flip (here: PTRenderPass/PTFlipFrames)
  * Scene: the Cornell box of SURVEY.md 8d (8 triangles, one rectangle light).
  *
- *   usage: pt_host [width height spp passes out.f32]     (writes width*height float4, linear radiance, row 0 = bottom)
+ *   usage: pt_host [width height spp passes out.f32 [abi_dump.bin]]
+ *          out.f32: width*height float4, linear radiance, row 0 = bottom.
+ *          abi_dump.bin: everything this host handed across the C-ABI, byte for byte -- the BuildBVH input, the attribute,
+ *          material and light arrays, the CWBVH the library returned, and the PTFrameParams of every pass -- so that a
+ *          checker can render the very same inputs (tests/test_gpu_parity.py::test_plain_c_host compares bit for bit).
  */
 #include <dlfcn.h>
 #include <math.h>
@@ -59,6 +63,9 @@ int main(int argc, char** argv)
     int W = argc > 1 ? atoi(argv[1]) : 256, H = argc > 2 ? atoi(argv[2]) : 256;
     int spp = argc > 3 ? atoi(argv[3]) : 1, passes = argc > 4 ? atoi(argv[4]) : 1;
     const char* out = argc > 5 ? argv[5] : NULL;
+    const char* dumpPath = argc > 6 ? argv[6] : NULL;
+    FILE* dump = dumpPath ? fopen(dumpPath, "wb") : NULL;
+    if (dumpPath && !dump) { fprintf(stderr, "cannot write %s\n", dumpPath); return 2; }
     const char* path = getenv("PT_PLUGIN");
     if (!path) path = "unity_webgpu_pathtracer_amd/lib/libunity-webgpu-pathtracer-plugin.so";
     void* lib = dlopen(path, RTLD_NOW);
@@ -91,12 +98,25 @@ int main(int argc, char** argv)
     if (h < 0 || !p_IsBVHReady(h)) { fprintf(stderr, "BuildBVH failed\n"); return 1; }
     PTFloat4 *nodes = NULL, *tris = NULL;
     p_GetCWBVHData(h, &nodes, &tris);
+    if (dump) {
+        /* header: magic, nodes bytes, tris bytes, triangles, materials, lights, passes, sizeof(PTFrameParams) */
+        const uint32_t hdr[8] = {0x44494250u, (uint32_t)p_GetCWBVHNodesSize(h), (uint32_t)p_GetCWBVHTrisSize(h), 8u, 3u, 1u,
+                                 (uint32_t)passes, (uint32_t)sizeof(PTFrameParams)};
+        fwrite(hdr, sizeof(hdr), 1, dump);
+        fwrite(verts, sizeof(verts), 1, dump);
+        fwrite(attrs, sizeof(attrs), 1, dump);
+        fwrite(mats, sizeof(mats), 1, dump);
+        fwrite(&light, sizeof(light), 1, dump);
+        fwrite(nodes, hdr[1], 1, dump);
+        fwrite(tris, hdr[2], 1, dump);
+    }
 
     PTContext* ctx = NULL;
     int rc = p_PTCreate(0, &ctx);
     if (rc) { fprintf(stderr, "PTCreate: %d %s\n", rc, p_PTGetLastError()); return 1; }
     PTSceneDesc sd;
     memset(&sd, 0, sizeof(sd));
+    sd.structSize = (uint32_t)sizeof(sd);
     sd.bvhNodes = nodes; sd.bvhNodesBytes = (uint64_t)p_GetCWBVHNodesSize(h);
     sd.bvhTris = tris;   sd.bvhTrisBytes = (uint64_t)p_GetCWBVHTrisSize(h);
     sd.triAttrs = attrs; sd.triAttrsBytes = sizeof(attrs);
@@ -109,6 +129,7 @@ int main(int argc, char** argv)
 
     PTFrameParams p;
     memset(&p, 0, sizeof(p));
+    p.structSize = (uint32_t)sizeof(p);
     float t = tanf(40.0f * 0.5f * 3.14159265f / 180.0f), aspect = (float)W / (float)H, n = 0.1f, f = 100.0f;
     /* inverse of the GL projection, Matrix4x4 memory order (element (r,c) at c*4+r) */
     p.CamInvProj[0] = t * aspect; p.CamInvProj[5] = t; p.CamInvProj[11] = (n - f) / (2.0f * f * n);
@@ -121,6 +142,7 @@ int main(int argc, char** argv)
     for (int k = 0; k < passes; k++) {              /* PathTracer.cs:224-272 */
         p.CurrentSample = (uint32_t)currentSample;
         p.RngSeedRoot = 0x12345678u + (uint32_t)k * 0x9E3779B9u;
+        if (dump) fwrite(&p, sizeof(p), 1, dump);
         rc = p_PTRenderPass(ctx, &p);
         if (rc) { fprintf(stderr, "PTRenderPass: %d %s\n", rc, p_PTGetLastError()); return 1; }
         currentSample += spp > 1 ? spp : 1;
@@ -139,6 +161,7 @@ int main(int argc, char** argv)
            (unsigned long long)(st.closestHitRays + st.shadowRays), mean[0] / (W * H), mean[1] / (W * H), mean[2] / (W * H));
     if (out) { FILE* fo = fopen(out, "wb"); if (fo) { fwrite(frame, sizeof(float), (size_t)W * H * 4, fo); fclose(fo); } }
     free(frame);
+    if (dump) fclose(dump);
     p_PTDestroy(ctx);
     dlclose(lib);
     return 0;

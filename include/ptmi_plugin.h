@@ -76,9 +76,17 @@ typedef struct PTContext PTContext;   /* opaque; one per GPU (one process per GP
 #define PT_FEATURE_HAS_TLAS      0x4u   /* HAS_TLAS     (BVHScene.cs:145-149): two-level traversal, util/tlas.hlsl       */
 #define PT_FEATURE_HAS_ENVIRONMENT_TEXTURE 0x8u   /* HAS_ENVIRONMENT_TEXTURE (PathTracer.cs:119-143): util/sky.hlsl:7-88 */
 
+/* Versioning of the two input structs: the FIRST member of PTSceneDesc and PTFrameParams is structSize = sizeof(the struct
+ * the host was compiled against).  New members are only ever appended; the library reads min(structSize, its own sizeof)
+ * bytes and treats the rest as zero, and rejects a structSize smaller than the first published layout (PT_ERR_INVALID_ARG:
+ * almost always a host that forgot to set it).  So a host built against an older header keeps working unchanged. */
+
 /* The buffers BVHScene.PrepareShader binds (BVHScene.cs:151-166) + Lights (PathTracer.cs:471).
- * All pointers are HOST pointers; PTSetScene copies them into HBM. */
+ * All pointers are HOST pointers; PTSetScene copies them into HBM and VALIDATES every index the kernels will follow
+ * (material indices, texture descriptors, CWBVH child / triangle ranges, primitive indices, TLAS nodes and instance offsets):
+ * a scene that would make a kernel read out of bounds is refused with PT_ERR_INVALID_ARG instead of faulting the GPU. */
 typedef struct PTSceneDesc {
+    uint32_t        structSize;      uint32_t _pad3;             /* = sizeof(PTSceneDesc) of the host's header */
     const void*     bvhNodes;        uint64_t bvhNodesBytes;     /* PTCwbvhNode[]          "BVHNodes" */
     const void*     bvhTris;         uint64_t bvhTrisBytes;      /* PTCwbvhTri[]           "BVHTris"  */
     const void*     triAttrs;        uint64_t triAttrsBytes;     /* PTTriangleAttributes[] "TriangleAttributesBuffer" */
@@ -99,12 +107,15 @@ typedef struct PTSceneDesc {
      * it picked.  (Sampler state and row order belong to Unity's platform layer: parity unpinned there, see DESIGN.md.) */
     const float*    envTexture;      uint32_t envWidth;  uint32_t envHeight;
 } PTSceneDesc;
+#define PT_SCENE_DESC_MIN_SIZE  ((uint32_t)(uintptr_t)&((PTSceneDesc*)0)->envTexture)      /* layout before the environment texture */
 
 /* The uniform block PathTracer.OnRenderImage sets every frame (PathTracer.cs:230-249;
  * declarations util/globals.hlsl:7-17, util/camera.hlsl:7-10, PathTracer.compute:40-41).
  * Matrices are 16 floats in Unity Matrix4x4 memory order: element (row r, col c) at [c*4+r],
  * applied to column vectors (mul(M, v)). */
 typedef struct PTFrameParams {
+    uint32_t structSize;              /* = sizeof(PTFrameParams) of the host's header (see "Versioning" above) */
+    uint32_t _pad0;
     float    CamInvProj[16];          /* _camera.projectionMatrix.inverse  (PathTracer.cs:230) */
     float    CamToWorld[16];          /* _camera.cameraToWorldMatrix       (PathTracer.cs:231) */
     uint32_t RngSeedRoot;             /* fresh random value per frame      (PathTracer.cs:233) */
@@ -116,7 +127,7 @@ typedef struct PTFrameParams {
     int32_t  EnvironmentMode;         /* 0 environment colour, 1 basic sky (PathTracer.cs:239) */
     float    EnvironmentIntensity;
     float    EnvironmentColor[4];
-    float    EnvironmentMapRotation;  /* only read by HAS_ENVIRONMENT_TEXTURE (not built)      */
+    float    EnvironmentMapRotation;  /* only read by HAS_ENVIRONMENT_TEXTURE (PathTracer.cs:243)  */
     float    FocalLength;
     float    Aperture;
     int32_t  UseFireflyFilter;
@@ -129,6 +140,7 @@ typedef struct PTFrameParams {
     uint32_t DispatchGroupsX;
     uint32_t DispatchGroupsY;
 } PTFrameParams;
+#define PT_FRAME_PARAMS_MIN_SIZE ((uint32_t)(uintptr_t)&((PTFrameParams*)0)->DispatchGroupsX) /* DispatchGroups default to 0, 0 */
 
 /* Work counters, accumulated over passes since the last PTResetStats.  One "ray" is one
  * call of RayIntersectBvh (util/bvh.hlsl:126): SURVEY.md §8(d). */

@@ -238,24 +238,47 @@ def test_render_pass_to_caller_buffers(oracle):
 
 
 def test_plain_c_host(tmp_path, oracle):
-    """host/pt_host.c: the plain-C host renders the Cornell box through the C-ABI; its frame equals the oracle's."""
+    """host/pt_host.c: the plain-C host renders the Cornell box through the C-ABI, two progressive passes.  It dumps every byte
+    it handed across the boundary (geometry, attributes, materials, light, the CWBVH it got back, each pass's PTFrameParams);
+    the oracle renders exactly those inputs and the frames must be bit-identical."""
+    import ctypes as C
     import os
     import subprocess
+    from unity_webgpu_pathtracer_amd import abi
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call(["make", "-C", os.path.join(root, "host")], stdout=subprocess.DEVNULL)
-    out = str(tmp_path / "frame.f32")
-    subprocess.check_call([os.path.join(root, "host", "pt_host"), "64", "48", "2", "2", out], cwd=root, stdout=subprocess.DEVNULL)
+    out, dump = str(tmp_path / "frame.f32"), str(tmp_path / "abi_dump.bin")
+    subprocess.check_call([os.path.join(root, "host", "pt_host"), "64", "48", "2", "2", out, dump], cwd=root, stdout=subprocess.DEVNULL)
     gpu = np.fromfile(out, dtype=np.float32).reshape(48, 64, 4)
-    s = scenes.cornell_box()
-    from unity_webgpu_pathtracer_amd import plugin
-    nodes, tris = plugin.build_cwbvh(s.vertices)
+    raw = open(dump, "rb").read()
+    hdr = np.frombuffer(raw, np.uint32, 8)
+    assert hdr[0] == 0x44494250 and hdr[7] == C.sizeof(abi.PTFrameParams)
+    nodes_b, tris_b, ntri, nmat, nlight, passes = (int(x) for x in hdr[1:7])
+    off = 32
+
+    def take(nbytes, dtype):
+        nonlocal off
+        a = np.frombuffer(raw, dtype, nbytes // np.dtype(dtype).itemsize, off).copy()
+        off += nbytes
+        return a
+    verts = take(ntri * 3 * 16, np.float32).reshape(-1, 4)
+    attrs = take(ntri * 128, abi.TRI_ATTR)
+    mats = take(nmat * 128, np.float32).reshape(nmat, 32)
+    lights = take(nlight * 64, np.float32).reshape(nlight, 16)
+    nodes, tris = take(nodes_b, np.uint8), take(tris_b, np.uint8)
+    ref_scene = scenes.cornell_box()
+    s = scenes.Scene("c_host_cornell", verts, attrs, mats, lights, np.zeros(0, np.uint32), ref_scene.camera)
     b = oracle.SceneBuffers(s, nodes, tris)
     ref = None
-    for k in range(2):
-        p = scenes.frame_params(s, 64, 48, spp=2, current_sample=2 * k, seed=(0x12345678 + k * 0x9E3779B9) & 0xFFFFFFFF)
+    for k in range(passes):
+        p = abi.PTFrameParams.from_buffer_copy(raw, off)
+        off += C.sizeof(abi.PTFrameParams)
+        assert p.structSize == C.sizeof(abi.PTFrameParams) and p.CurrentSample == 2 * k
         ref, _ = oracle.render(b, p, accumulated=ref)
-    # the C host computes its camera matrices in fp32 C arithmetic, the Python host in fp64 numpy: allow that difference
-    assert np.abs(gpu - ref).mean() < 0.05 and gpu.shape == ref.shape and np.isfinite(gpu).all()
+    assert off == len(raw)
+    assert np.array_equal(gpu.view(np.uint32), ref.view(np.uint32))
+    # and the C host's scene is the Python generator's Cornell box up to fp32-vs-fp64 rounding of the host-side setup
+    assert np.allclose(mats, ref_scene.materials, rtol=1e-5) and np.allclose(verts, ref_scene.vertices)
 
 
 @pytest.mark.parametrize("schedule", SCHEDULES)
@@ -366,6 +389,70 @@ def test_full_size_frame_windows_and_properties(oracle):
     pt.close()
 
 
+def _windows_vs_oracle(oracle, scene, W, H, SPP, windows, seeds, bounces=4):
+    """Renders len(seeds) progressive passes of `scene` at W x H x SPP through the C-ABI and compares `windows` of every pass
+    with the oracle bit for bit (each pass reading the GPU's previous frame as AccumulatedOutput at its own pixels).  Returns
+    the frames and the stats."""
+    pt = PathTracer(scene, width=W, height=H, samplesPerPass=SPP, maxRayBounces=bounces)
+    b = oracle.buffers_from_bvhscene(pt._bvhScene)
+    frames, params = [], []
+    for seed in seeds:
+        params.append(pt.params(seed))
+        pt.OnRenderImage(seed)
+        frames.append(pt.readback())
+    st = pt.stats()
+    for k, (p, f) in enumerate(zip(params, frames)):
+        assert np.isfinite(f).all() and (f[..., 3] == 1.0).all() and (f[..., :3] >= 0).all()
+        for (x0, y0, x1, y1) in windows:
+            r, _ = oracle.render(b, p, accumulated=frames[k - 1] if k else None, window=(x0, y0, x1, y1))
+            assert np.array_equal(f[y0:y1, x0:x1].view(np.uint32), r[y0:y1, x0:x1].view(np.uint32)), (scene.name, k, x0, y0)
+    assert st.paths == len(seeds) * W * H * SPP and st.pixelsWritten == len(seeds) * W * H
+    pt.close()
+    return frames, st
+
+
+def test_c2_cornell_1080p_8spp_windows(oracle):
+    """BASELINE.json configs[1]: Cornell box 1920x1080, 8 spp, depth 4 -- FULL size (auto schedule = megakernel for this scene)."""
+    s = scenes.cornell_box()
+    wins = [(0, 0, 32, 16), (944, 532, 976, 548), (1888, 1064, 1920, 1080), (400, 100, 432, 116), (1300, 900, 1332, 916)]
+    _windows_vs_oracle(oracle, s, 1920, 1080, 8, wins, [0x12345678, (0x12345678 + 0x9E3779B9) & 0xFFFFFFFF])
+
+
+def test_c3_bunny_1080p_8spp_windows(oracle):
+    """BASELINE.json configs[2]: bunny-class (69,620-triangle displaced icosphere in the Cornell box) 1920x1080, 8 spp -- FULL
+    size, the scene bench.py times under other_workloads."""
+    s = scenes.make_scene("bunny")
+    assert 69_000 < s.tri_count < 70_500
+    wins = [(0, 0, 24, 12), (948, 534, 972, 546), (1896, 1068, 1920, 1080), (800, 400, 824, 412), (1100, 640, 1124, 652), (960, 300, 984, 312)]
+    _windows_vs_oracle(oracle, s, 1920, 1080, 8, wins, [0x12345678, (0x12345678 + 0x9E3779B9) & 0xFFFFFFFF])
+
+
+def test_c4_benched_sponza_tex1024_windows_and_bench_crc(oracle):
+    """The scene bench.py BENCHES (BASELINE.json configs[3]): Sponza-class with its 24 x 1024^2 textures (the 100 MB atlas, its
+    offsets, the (float)width - 1 arithmetic at 1024), 1920x1080, 8 spp, depth 4, bench.py's seeds and pass schedule.  Windows
+    equal the oracle bit for bit, and the frame's CRC-32 is computed the way bench.py computes config.frame_crc32, from the
+    same scene constructor and seed schedule, so the benched frame IS a checked frame."""
+    import zlib
+    import bench
+    wl = bench.WORKLOADS["sponza"]
+    assert wl["kw"]["tex_size"] == 1024
+    s = scenes.make_scene(wl["scene"], **wl["kw"])
+    assert s.texture_data.nbytes > 100e6
+    seeds = [bench.seed_of(k) for k in range(3)]
+    wins = [(0, 0, 24, 12), (948, 534, 972, 546), (1896, 1068, 1920, 1080), (300, 900, 324, 912), (1500, 200, 1524, 212), (700, 40, 724, 52)]
+    frames, _ = _windows_vs_oracle(oracle, s, 1920, 1080, 8, wins, seeds)
+    # bench.py --steps 2 --warmup 1 ends on pass index 2 and prints the CRC-32 of that frame
+    crc = zlib.crc32(frames[2].tobytes())
+    print(f"[parity] benched sponza frame after passes 0..2: crc32 = {crc}")
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-extra", "--no-cpu-baseline", "--no-alg-replay"],
+                         capture_output=True, text=True, cwd=root, timeout=600)
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert line, out.stderr[-2000:]
+    assert json.loads(line[-1])["config"]["frame_crc32"] == crc
+
+
 def test_api_error_behaviour():
     """Every PT* entry point returns 0 or a negative PT_ERR_* code with a message; nothing is rendered on bad input."""
     import ctypes as C
@@ -404,6 +491,17 @@ def test_api_error_behaviour():
     assert lib.PTRenderPassTo(pt.ctx, C.byref(p), None, None) == abi.PT_ERR_INVALID_ARG
     assert lib.PTSetSchedule(pt.ctx, 9) == abi.PT_ERR_UNSUPPORTED and lib.PTSetSchedule(pt.ctx, -1) == abi.PT_OK
     assert lib.PTSetTileOwnership(pt.ctx, 3, 2) == abi.PT_ERR_INVALID_ARG
+    # "Versioning": a host that does not set structSize is refused, one built against an older (shorter) header is served
+    unsized = pt._bvhScene.desc()
+    unsized.structSize = 0
+    assert lib.PTSetScene(pt.ctx, C.byref(unsized)) == abi.PT_ERR_INVALID_ARG and b"structSize" in lib.PTGetLastError()
+    older = pt._bvhScene.desc()
+    older.structSize = abi.PTSceneDesc.envTexture.offset            # the layout before the environment-texture members
+    older.envTexture, older.envWidth = 0xDEAD0000, 7                # must be ignored: beyond the host's structSize
+    assert lib.PTSetScene(pt.ctx, C.byref(older)) == abi.PT_OK
+    nop = scenes.frame_params(s, 64, 64)
+    nop.structSize = 0
+    assert lib.PTRenderPass(pt.ctx, C.byref(nop)) == abi.PT_ERR_INVALID_ARG and b"structSize" in lib.PTGetLastError()
     many = scenes.frame_params(s, 64, 64, spp=5000)
     assert lib.PTSetSchedule(pt.ctx, 1) == abi.PT_OK
     assert lib.PTRenderPass(pt.ctx, C.byref(many)) == abi.PT_ERR_UNSUPPORTED          # the wavefront packs spp into 12 bits
@@ -413,6 +511,68 @@ def test_api_error_behaviour():
     assert lib.PTSetSchedule(pt.ctx, -1) == abi.PT_OK
     pt.render_pass(pt.params(seed=5))
     assert np.isfinite(pt.readback()).all()
+    pt.close()
+
+
+def test_scene_with_bad_indices_is_refused():
+    """PTSetScene follows every index the kernels will follow (D3D / WebGPU return zeros for an out-of-range read, a HIP kernel
+    faults the GPU): a bad material index, texture descriptor, CWBVH child / triangle range, primitive index, TLAS index or
+    instance offset is PT_ERR_INVALID_ARG, and the context keeps rendering the previous scene."""
+    import ctypes as C
+    from unity_webgpu_pathtracer_amd import abi, plugin
+    lib = plugin.load_library()
+    s = scenes.material_zoo()
+    pt = PathTracer(s, width=48, height=32, samplesPerPass=1)
+    pt.render_pass(pt.params(seed=1))
+    good = pt.readback().copy()
+    bs = pt._bvhScene
+
+    def refused(desc, what):
+        rc = lib.PTSetScene(pt.ctx, C.byref(desc))
+        assert rc == abi.PT_ERR_INVALID_ARG, (what, rc)
+        assert what.encode() in lib.PTGetLastError(), (what, lib.PTGetLastError())
+
+    attrs = bs.scene.tri_attrs.copy()
+    attrs["materialIndex"][5] = 10_000
+    d = bs.desc(); d.triAttrs = attrs.ctypes.data
+    refused(d, "materialIndex")
+    mats = np.ascontiguousarray(bs.scene.materials, np.float32).copy()
+    mats[0, 22] = 4000.0                                           # base-colour texture slot -> no such descriptor
+    d = bs.desc(); d.materials = mats.ctypes.data
+    refused(d, "texture index")
+    tex = bs.scene.texture_data.copy()
+    tex[2] = tex.size - 3                                          # descriptor 0: offset + w*h runs past the end
+    d = bs.desc(); d.textureData = tex.ctypes.data
+    refused(d, "descriptor")
+    nodes = np.frombuffer(bs.bvh_nodes.tobytes(), abi.CWBVH_NODE).copy()
+    k = int(np.nonzero(nodes["imask"])[0][0])
+    nodes["childBaseIndex"][k] = len(nodes)                        # children past the node array
+    d = bs.desc(); d.bvhNodes = nodes.ctypes.data
+    refused(d, "child index")
+    nodes = np.frombuffer(bs.bvh_nodes.tobytes(), abi.CWBVH_NODE).copy()
+    leafy = int(np.nonzero((nodes["meta"] != 0).any(axis=1) & (nodes["imask"] == 0))[0][0])
+    nodes["triBaseIndex"][leafy] = 0x7FFFFFF0
+    d = bs.desc(); d.bvhNodes = nodes.ctypes.data
+    refused(d, "triangle rows")
+    tris = np.frombuffer(bs.bvh_tris.tobytes(), np.uint32).copy().reshape(-1, 4)
+    tris[2, 3] = 0x00FFFFFF                                        # primitive index of triangle 0
+    d = bs.desc(); d.bvhTris = tris.ctypes.data
+    refused(d, "primitive index")
+    pt.render_pass(pt.params(seed=1))                              # the old scene is still there and still renders the same bits
+    assert np.array_equal(pt.readback().view(np.uint32), good.view(np.uint32))
+    pt.close()
+    # HAS_TLAS: instance offsets and TLAS indices
+    si = scenes.instanced_scene(count=5, detail=6)
+    pt = PathTracer(si, width=32, height=32, samplesPerPass=1)
+    bs = pt._bvhScene
+    inst = bs.gpu_instances.copy()
+    inst["bvhOffset"][1] = 1 << 28
+    d = bs.desc(); d.gpuInstances = inst.ctypes.data
+    refused(d, "instance 1")
+    tl = bs.tlas_data.copy()
+    tl.view(np.uint32)[bs.tlas_index_offset] = 99
+    d = bs.desc(); d.tlasData = tl.ctypes.data
+    refused(d, "TLAS index")
     pt.close()
 
 

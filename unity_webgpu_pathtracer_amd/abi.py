@@ -64,8 +64,16 @@ PT_ERR_NO_SCENE = -4
 PT_ERR_UNSUPPORTED = -5
 
 
-class PTSceneDesc(C.Structure):
+class _Sized(C.Structure):
+    """PTSceneDesc / PTFrameParams start with structSize = sizeof(struct) (include/ptmi_plugin.h, "Versioning")."""
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.structSize = C.sizeof(type(self))
+
+
+class PTSceneDesc(_Sized):
     _fields_ = [
+        ("structSize", C.c_uint32), ("_pad3", C.c_uint32),
         ("bvhNodes", C.c_void_p), ("bvhNodesBytes", C.c_uint64),
         ("bvhTris", C.c_void_p), ("bvhTrisBytes", C.c_uint64),
         ("triAttrs", C.c_void_p), ("triAttrsBytes", C.c_uint64),
@@ -80,8 +88,9 @@ class PTSceneDesc(C.Structure):
     ]
 
 
-class PTFrameParams(C.Structure):
+class PTFrameParams(_Sized):
     _fields_ = [
+        ("structSize", C.c_uint32), ("_pad0", C.c_uint32),
         ("CamInvProj", C.c_float * 16),
         ("CamToWorld", C.c_float * 16),
         ("RngSeedRoot", C.c_uint32),

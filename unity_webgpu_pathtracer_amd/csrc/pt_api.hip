@@ -38,7 +38,8 @@ int fail(int code, const std::string& msg)
 
 struct DeviceBuffer {
     void* ptr = nullptr;
-    size_t bytes = 0;
+    size_t bytes = 0;           // allocation capacity (a smaller scene re-uses it)
+    size_t used = 0;            // bytes of the scene currently uploaded
 };
 
 struct EventPair { hipEvent_t start, stop; uint32_t launches; };
@@ -81,6 +82,7 @@ namespace {
 int upload(PTContext* c, DeviceBuffer& b, const void* src, size_t bytes)
 {
     if (b.ptr && b.bytes < bytes) { hipFree(b.ptr); b.ptr = nullptr; b.bytes = 0; }
+    b.used = bytes;
     if (bytes == 0) return PT_OK;
     if (!b.ptr) {
         HIP_TRY(hipMalloc(&b.ptr, bytes));
@@ -152,6 +154,122 @@ int ensure_wavefront(PTContext* c, PTContext::WfSet& set, uint32_t numSlots, uin
     return PT_OK;
 }
 
+// One host pass over everything the kernels will index with scene data (D3D / WebGPU robust buffer access returns zeros for
+// an out-of-range read; a HIP kernel faults the GPU): triangle -> material, material -> texture descriptor -> texels,
+// CWBVH node -> child nodes / triangle rows, triangle row -> attribute record, TLAS node -> nodes / instances, instance ->
+// BLAS offsets.  Costs a few milliseconds for a 250k-triangle scene, once per PTSetScene.
+bool validate_scene(const PTSceneDesc& s, std::string& why)
+{
+    const uint64_t nodeCount = s.bvhNodesBytes / 80u, triRows = s.bvhTrisBytes / 16u, attrCount = s.triAttrsBytes / 128u;
+    const bool textures = (s.features & PT_FEATURE_HAS_TEXTURES) != 0, tlasOn = (s.features & PT_FEATURE_HAS_TLAS) != 0;
+    auto bad = [&](const std::string& m) { why = m; return false; };
+    // materials -> textures (util/material.hlsl:8-82 reads the five slots as float indices; < 0 = none)
+    const float* mats = (const float*)s.materials;
+    for (uint32_t m = 0; m < s.materialCount; ++m) {
+        const int slots[4] = {22, 23, 25, 26};                            // baseColor, metallicRoughness, emission, occlusion (normal map is unused)
+        for (int k : slots) {
+            const float f = mats[(size_t)m * 32 + k];
+            if (!textures || f < 0.0f) continue;
+            if (!(f < 1.0e9f)) return bad("material " + std::to_string(m) + ": texture index is not a finite number");
+            const uint64_t t = (uint64_t)f;
+            if (4 * t + 3 >= s.textureDataUints) return bad("material " + std::to_string(m) + ": texture index " + std::to_string(t) + " has no descriptor");
+            const uint32_t* d = s.textureData + 4 * t;
+            if (d[0] == 0 || d[1] == 0 || (uint64_t)d[2] + (uint64_t)d[0] * d[1] > s.textureDataUints)
+                return bad("texture " + std::to_string(t) + ": descriptor {w, h, offset} reaches outside textureData");
+        }
+    }
+    // triangles -> materials
+    const uint8_t* attrs = (const uint8_t*)s.triAttrs;
+    if (!tlasOn)
+        for (uint64_t i = 0; i < attrCount; ++i) {
+            uint32_t mi;
+            memcpy(&mi, attrs + i * 128 + 120, 4);
+            if (mi >= s.materialCount) return bad("triangle " + std::to_string(i) + ": materialIndex " + std::to_string(mi) + " >= materialCount");
+        }
+    // CWBVH: children, triangle rows, primitive indices.  With HAS_TLAS the arrays hold several BLASes back to back and every
+    // instance adds its own offsets: check each instance's range (below) and each node relative to the WHOLE arrays here.
+    const uint8_t* nodes = (const uint8_t*)s.bvhNodes;
+    const float* tris = (const float*)s.bvhTris;
+    for (uint64_t n = 0; n < nodeCount; ++n) {
+        const uint8_t* p = nodes + n * 80;
+        uint32_t childBase, triBase;
+        memcpy(&childBase, p + 16, 4);
+        memcpy(&triBase, p + 20, 4);
+        const uint8_t imask = p[15];
+        const uint8_t* meta = p + 24;
+        uint32_t inner = 0, maxTriRow = 0;
+        bool anyLeaf = false;
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t m = meta[i];
+            if (m == 0) continue;
+            if ((m & 0x18u) == 0x18u && (m >> 5) == 1u) { inner++; continue; }      // inner: (1 << 5) | (24 + slot)
+            anyLeaf = true;
+            const uint32_t first = m & 31u, count = (uint32_t)__builtin_popcount(m >> 5);
+            const uint32_t last = (first + count) * 3u;
+            if (last > maxTriRow) maxTriRow = last;
+        }
+        if (inner != (uint32_t)__builtin_popcount(imask)) return bad("node " + std::to_string(n) + ": imask does not match its inner children");
+        if (!tlasOn) {
+            if (inner && (uint64_t)childBase + inner > nodeCount) return bad("node " + std::to_string(n) + ": child index past the node array");
+            if (anyLeaf && (uint64_t)triBase + maxTriRow > triRows) return bad("node " + std::to_string(n) + ": triangle rows past the triangle array");
+        }
+    }
+    if (!tlasOn)
+        for (uint64_t t = 0; t + 2 < triRows; t += 3) {
+            uint32_t prim;
+            memcpy(&prim, tris + (t + 2) * 4 + 3, 4);
+            if (prim >= attrCount) return bad("triangle row " + std::to_string(t) + ": primitive index " + std::to_string(prim) + " has no attribute record");
+        }
+    if (tlasOn) {
+        const uint64_t tlasNodes = s.tlasIndexOffset / 16u, indices = s.tlasDataFloats - s.tlasIndexOffset;
+        const uint32_t* T = (const uint32_t*)s.tlasData;
+        for (uint64_t n = 0; n < tlasNodes; ++n) {
+            const uint32_t left = T[n * 16 + 3], right = T[n * 16 + 7], count = T[n * 16 + 11], first = T[n * 16 + 15];
+            if (count == 0) { if (left >= tlasNodes || right >= tlasNodes) return bad("TLAS node " + std::to_string(n) + ": child index past the TLAS nodes"); }
+            else if ((uint64_t)first + count > indices) return bad("TLAS node " + std::to_string(n) + ": instance range past the index list");
+        }
+        for (uint64_t i = 0; i < indices; ++i)
+            if (T[s.tlasIndexOffset + i] >= s.instanceCount) return bad("TLAS index " + std::to_string(i) + " >= instanceCount");
+        const uint8_t* inst = (const uint8_t*)s.gpuInstances;
+        for (uint32_t i = 0; i < s.instanceCount; ++i) {
+            int32_t off[4];
+            memcpy(off, inst + (size_t)i * 144 + 128, 16);
+            if (off[0] < 0 || (uint64_t)off[0] >= nodeCount || off[1] < 0 || (uint64_t)off[1] > triRows || off[2] < 0 || (uint64_t)off[2] > attrCount ||
+                off[3] < 0 || (uint32_t)off[3] >= s.materialCount)
+                return bad("instance " + std::to_string(i) + ": bvhOffset / triOffset / triAttributeOffset / materialIndex out of range");
+            // walk the instance's BLAS from its root: every node, triangle row and primitive index it can reach must exist
+            std::vector<uint32_t> todo(1, 0u);
+            uint64_t visited = 0;
+            while (!todo.empty()) {
+                const uint32_t rel = todo.back();
+                todo.pop_back();
+                if (++visited > nodeCount) return bad("instance " + std::to_string(i) + ": BLAS node graph is not a tree");
+                const uint64_t n = (uint64_t)off[0] + rel;
+                if (n >= nodeCount) return bad("instance " + std::to_string(i) + ": BLAS child index past the node array");
+                const uint8_t* p = nodes + n * 80;
+                uint32_t childBase, triBase;
+                memcpy(&childBase, p + 16, 4);
+                memcpy(&triBase, p + 20, 4);
+                uint32_t inner = 0;
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t m = p[24 + k];
+                    if (m == 0) continue;
+                    if ((m & 0x18u) == 0x18u && (m >> 5) == 1u) { todo.push_back(childBase + inner); inner++; continue; }
+                    const uint32_t first = m & 31u, count = (uint32_t)__builtin_popcount(m >> 5);
+                    for (uint32_t q = first; q < first + count; ++q) {
+                        const uint64_t row = (uint64_t)off[1] + triBase + (uint64_t)q * 3u;
+                        if (row + 2 >= triRows) return bad("instance " + std::to_string(i) + ": triangle rows past the triangle array");
+                        uint32_t prim;
+                        memcpy(&prim, tris + (row + 2) * 4 + 3, 4);
+                        if ((uint64_t)off[2] + prim >= attrCount) return bad("instance " + std::to_string(i) + ": primitive index has no attribute record");
+                    }
+                }
+            }
+        }
+    }
+    return true;
+}
+
 int drain_events(PTContext* c)
 {
     for (auto& ep : c->pending) {
@@ -168,6 +286,18 @@ int drain_events(PTContext* c)
     return PT_OK;
 }
 
+// "Versioning" (include/ptmi_plugin.h): copy min(structSize, sizeof) bytes of the host's struct into a zeroed one of ours
+int import_params(const PTFrameParams* in, PTFrameParams& p)
+{
+    if (!in) return fail(PT_ERR_INVALID_ARG, "params == NULL");
+    if (in->structSize < PT_FRAME_PARAMS_MIN_SIZE || in->structSize > 4096u)
+        return fail(PT_ERR_INVALID_ARG, "PTFrameParams.structSize is not set (must be sizeof(PTFrameParams) of the host's header)");
+    memset(&p, 0, sizeof(p));
+    memcpy(&p, in, in->structSize < sizeof(p) ? in->structSize : sizeof(p));
+    p.structSize = (uint32_t)sizeof(p);
+    return PT_OK;
+}
+
 int validate_params(const PTFrameParams* p)
 {
     if (!p) return fail(PT_ERR_INVALID_ARG, "params == NULL");
@@ -181,14 +311,17 @@ int validate_params(const PTFrameParams* p)
 int effective_schedule(const PTContext* c)
 {
     if (c->schedule >= 0) return c->schedule;
-    return (c->nodes.bytes <= 80u * 16u && !c->scene.hasTlas) ? 0 : 1;
+    return (c->nodes.used <= 80u * 16u && !c->scene.hasTlas) ? 0 : 1;
 }
 
-int render_to(PTContext* c, const PTFrameParams* p, float4* dOut, const float4* dAcc)
+int render_to(PTContext* c, const PTFrameParams* hostParams, float4* dOut, const float4* dAcc)
 {
     if (!c) return fail(PT_ERR_INVALID_ARG, "ctx == NULL");
-    int rc = validate_params(p);
+    PTFrameParams params;
+    int rc = import_params(hostParams, params);
     if (rc) return rc;
+    const PTFrameParams* p = &params;
+    if ((rc = validate_params(p))) return rc;
     if (!c->hasScene) return fail(PT_ERR_NO_SCENE, "PTSetScene has not been called");
     if (!dOut) return fail(PT_ERR_INVALID_ARG, "output buffer == NULL");
     if (p->CurrentSample > 0 && !dAcc) return fail(PT_ERR_INVALID_ARG, "CurrentSample > 0 needs an accumulated frame");
@@ -300,9 +433,15 @@ PT_API int PTDestroy(PTContext* c)
     return PT_OK;
 }
 
-PT_API int PTSetScene(PTContext* c, const PTSceneDesc* s)
+PT_API int PTSetScene(PTContext* c, const PTSceneDesc* hostScene)
 {
-    if (!c || !s) return fail(PT_ERR_INVALID_ARG, "ctx/scene == NULL");
+    if (!c || !hostScene) return fail(PT_ERR_INVALID_ARG, "ctx/scene == NULL");
+    if (hostScene->structSize < PT_SCENE_DESC_MIN_SIZE || hostScene->structSize > 4096u)
+        return fail(PT_ERR_INVALID_ARG, "PTSceneDesc.structSize is not set (must be sizeof(PTSceneDesc) of the host's header)");
+    PTSceneDesc sceneCopy;
+    memset(&sceneCopy, 0, sizeof(sceneCopy));
+    memcpy(&sceneCopy, hostScene, hostScene->structSize < sizeof(sceneCopy) ? hostScene->structSize : sizeof(sceneCopy));
+    const PTSceneDesc* s = &sceneCopy;
     const bool tlasOn = (s->features & PT_FEATURE_HAS_TLAS) != 0;
     if (tlasOn && (!s->tlasData || s->tlasDataFloats < 16 || !s->gpuInstances || s->instanceCount == 0 ||
                    s->tlasIndexOffset >= s->tlasDataFloats || s->tlasIndexOffset % 16 != 0))
@@ -316,6 +455,10 @@ PT_API int PTSetScene(PTContext* c, const PTSceneDesc* s)
     const bool envOn = (s->features & PT_FEATURE_HAS_ENVIRONMENT_TEXTURE) != 0;
     if (envOn && (!s->envTexture || s->envWidth == 0 || s->envHeight == 0 || (uint64_t)s->envWidth * s->envHeight > 0x7FFFFFFFull))
         return fail(PT_ERR_INVALID_ARG, "HAS_ENVIRONMENT_TEXTURE needs envTexture, envWidth, envHeight");
+    {
+        std::string why;
+        if (!validate_scene(*s, why)) return fail(PT_ERR_INVALID_ARG, "scene refused: " + why);
+    }
     HIP_TRY(hipSetDevice(c->device));
     for (auto& set : c->sets) if (set.stream) HIP_TRY(hipStreamSynchronize(set.stream));   // no pass may still read the old scene
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -377,11 +520,14 @@ PT_API int PTSetTileOwnership(PTContext* c, int rank, int worldSize)
     return PT_OK;
 }
 
-PT_API int PTRenderPass(PTContext* c, const PTFrameParams* p)
+PT_API int PTRenderPass(PTContext* c, const PTFrameParams* hostParams)
 {
     if (!c) return fail(PT_ERR_INVALID_ARG, "ctx == NULL");
-    int rc = validate_params(p);
+    PTFrameParams params;
+    int rc = import_params(hostParams, params);
     if (rc) return rc;
+    const PTFrameParams* p = &params;
+    if ((rc = validate_params(p))) return rc;
     HIP_TRY(hipSetDevice(c->device));
     if ((rc = ensure_frames(c, p->OutputWidth, p->OutputHeight))) return rc;
     return render_to(c, p, c->frames[c->cur], c->frames[1 - c->cur]);
