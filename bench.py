@@ -10,8 +10,10 @@ frames are resident in HBM before the timed region.  One ray = one RayIntersectB
 shadow ray); the count comes from the kernels' own always-on counters, which the parity tests pin to the oracle's.
 
 N > 1: one process per GPU; the frame is sharded as interleaved 16x16-pixel blocks (PTSetTileOwnership), every
-rank renders only its blocks and the partial frames are summed onto rank 0 with ONE RCCL reduce per step (exact:
-non-owned pixels are zeros).  The total work is fixed as N grows -> "scaling": "strong".
+rank renders only its blocks, packs them densely (PTPackOwnedTiles) and ONE RCCL gather per step moves the packed
+tiles -- 1/N of the frame per rank -- to rank 0, which scatters them into the assembled frame (PTUnpackTiles).  No
+float is added anywhere, so the frame is bit-identical for every N.  The total work is fixed as N grows ->
+"scaling": "strong".
 
 Rank 0 prints ONE JSON line.  `roofline` prices the render kernel against the 8 TB/s HBM peak with ALGORITHMIC
 bytes (SURVEY.md 8d formula over the kernel's own node/triangle/attribute/material/texel counters) divided by the
@@ -38,6 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+from unity_webgpu_pathtracer_amd import distributed as dist_helpers  # noqa: E402
 from unity_webgpu_pathtracer_amd import scenes  # noqa: E402
 from unity_webgpu_pathtracer_amd.pathtracer import PathTracer  # noqa: E402
 
@@ -158,8 +161,9 @@ def main():
             pt.set_wavefront_iterations(args.wf_iterations)
         frames = [torch.zeros((H, W, 4), dtype=torch.float32, device=device) for _ in range(2)]
         # N > 1: the rank's two frames keep its own tiles (they are the next pass's AccumulatedOutput); the frame is
-        # assembled on rank 0 in a third buffer, so nothing depends on what a reduce leaves in non-root buffers
-        assembled = torch.zeros((H, W, 4), dtype=torch.float32, device=device) if distributed else None
+        # assembled on rank 0 in a third buffer from every rank's packed tiles
+        assembled = torch.zeros((H, W, 4), dtype=torch.float32, device=device) if (distributed and rank == 0) else None
+        scratch = {}
         ext = torch.cuda.ExternalStream(pt.stream(), device=device)
         torch.cuda.synchronize(device)
 
@@ -167,9 +171,8 @@ def main():
             p = scenes.frame_params(scene, W, H, spp=SPP, current_sample=k * SPP, seed=seed_of(k), max_bounces=args.bounces)
             pt.render_pass_to(p, frames[cur].data_ptr(), frames[1 - cur].data_ptr() if k > 0 else 0)
             if distributed:
-                with torch.cuda.stream(ext):
-                    assembled.copy_(frames[cur], non_blocking=True)
-                    dist.reduce(assembled, dst=0, op=dist.ReduceOp.SUM)       # RCCL over xGMI, once per frame
+                with torch.cuda.stream(ext):                                  # pack -> RCCL gather over xGMI -> unpack, once per frame
+                    dist_helpers.gather_frame(frames[cur], rank, world, dst=0, assembled=assembled, pt=pt, params=p, scratch=scratch)
 
         def sync_all():
             pt.synchronize()
@@ -278,7 +281,7 @@ def main():
                        "tris": main_res["tris"], "rays_per_step": round(main_res["rays_per_step"]),
                        "msamples_per_s": round(main_res["msamples_per_s"], 3), "schedule": main_res["schedule"],
                        "frame_crc32": main_res["frame_crc32"],
-                       "sharding": "interleaved 16x16 blocks, one RCCL reduce per frame" if distributed else "single GPU"},
+                       "sharding": "interleaved 16x16 blocks, one RCCL gather of owned tiles per frame" if distributed else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                          "kernel": {0: "pt_megakernel", 1: "pt_wf_trace_refill + pt_wf_shade (whole pass)", 2: "pt_wf_trace + pt_wf_shade (whole pass)",

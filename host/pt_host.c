@@ -6,6 +6,8 @@
  * Scene: the Cornell box of SURVEY.md 8d (8 triangles, one rectangle light).
  *
  *   usage: pt_host [width height spp passes out.f32 [abi_dump.bin]]
+ *          PT_HOST_DEVICES=0,1,2,3 (environment): render on those devices through PTCreateMulti / PTGroup* -- one process, N
+ *          GPUs, frame assembled in the library from every device's tiles; the same device may be listed twice.
  *          out.f32: width*height float4, linear radiance, row 0 = bottom.
  *          abi_dump.bin: everything this host handed across the C-ABI, byte for byte -- the BuildBVH input, the attribute,
  *          material and light arrays, the CWBVH the library returned, and the PTFrameParams of every pass -- so that a
@@ -73,6 +75,15 @@ int main(int argc, char** argv)
     LOAD(BuildBVH) LOAD(DestroyBVH) LOAD(IsBVHReady) LOAD(GetCWBVHNodesSize) LOAD(GetCWBVHTrisSize) LOAD(GetCWBVHData)
     LOAD(PTCreate) LOAD(PTDestroy) LOAD(PTSetScene) LOAD(PTRenderPass) LOAD(PTFlipFrames) LOAD(PTReadback)
     LOAD(PTGetStats) LOAD(PTGetLastError) LOAD(PTSynchronize)
+    LOAD(PTCreateMulti) LOAD(PTGroupDestroy) LOAD(PTGroupSetScene) LOAD(PTGroupRenderPass) LOAD(PTGroupFlipFrames) LOAD(PTGroupReadback)
+    LOAD(PTGroupGetStats)
+    int devices[64], nDevices = 0;
+    const char* devList = getenv("PT_HOST_DEVICES");
+    if (devList && *devList) {
+        char* copy = strdup(devList);
+        for (char* tok = strtok(copy, ","); tok && nDevices < 64; tok = strtok(NULL, ",")) devices[nDevices++] = atoi(tok);
+        free(copy);
+    }
 
     PTFloat4 verts[24];
     PTTriangleAttributes attrs[8];
@@ -112,8 +123,9 @@ int main(int argc, char** argv)
     }
 
     PTContext* ctx = NULL;
-    int rc = p_PTCreate(0, &ctx);
-    if (rc) { fprintf(stderr, "PTCreate: %d %s\n", rc, p_PTGetLastError()); return 1; }
+    PTGroup* group = NULL;
+    int rc = nDevices ? p_PTCreateMulti(devices, nDevices, &group) : p_PTCreate(0, &ctx);
+    if (rc) { fprintf(stderr, "PTCreate%s: %d %s\n", nDevices ? "Multi" : "", rc, p_PTGetLastError()); return 1; }
     PTSceneDesc sd;
     memset(&sd, 0, sizeof(sd));
     sd.structSize = (uint32_t)sizeof(sd);
@@ -123,7 +135,7 @@ int main(int argc, char** argv)
     sd.materials = mats; sd.materialCount = 3;
     sd.lights = &light;  sd.lightCount = 1;
     sd.features = PT_FEATURE_HAS_LIGHTS;
-    rc = p_PTSetScene(ctx, &sd);
+    rc = group ? p_PTGroupSetScene(group, &sd) : p_PTSetScene(ctx, &sd);
     if (rc) { fprintf(stderr, "PTSetScene: %d %s\n", rc, p_PTGetLastError()); return 1; }
     p_DestroyBVH(h);                                /* the C# host frees the BVH right after upload (BVHScene.cs:764-766) */
 
@@ -143,18 +155,18 @@ int main(int argc, char** argv)
         p.CurrentSample = (uint32_t)currentSample;
         p.RngSeedRoot = 0x12345678u + (uint32_t)k * 0x9E3779B9u;
         if (dump) fwrite(&p, sizeof(p), 1, dump);
-        rc = p_PTRenderPass(ctx, &p);
+        rc = group ? p_PTGroupRenderPass(group, &p) : p_PTRenderPass(ctx, &p);
         if (rc) { fprintf(stderr, "PTRenderPass: %d %s\n", rc, p_PTGetLastError()); return 1; }
         currentSample += spp > 1 ? spp : 1;
         flipped = 0;
-        if (currentSample < maxSamples && k + 1 < passes) { p_PTFlipFrames(ctx); flipped = 1; }
+        if (currentSample < maxSamples && k + 1 < passes) { if (group) p_PTGroupFlipFrames(group); else p_PTFlipFrames(ctx); flipped = 1; }
     }
     (void)flipped;
     float* frame = (float*)malloc((size_t)W * H * 4 * sizeof(float));
-    rc = p_PTReadback(ctx, frame, (uint64_t)W * H * 4);
+    rc = group ? p_PTGroupReadback(group, frame, (uint64_t)W * H * 4) : p_PTReadback(ctx, frame, (uint64_t)W * H * 4);
     if (rc) { fprintf(stderr, "PTReadback: %d %s\n", rc, p_PTGetLastError()); return 1; }
     PTStats st;
-    p_PTGetStats(ctx, &st);
+    if (group) p_PTGroupGetStats(group, &st); else p_PTGetStats(ctx, &st);
     double mean[3] = {0, 0, 0};
     for (long i = 0; i < (long)W * H; i++) for (int c = 0; c < 3; c++) mean[c] += frame[i * 4 + c];
     printf("pt_host: %dx%d, %d spp x %d passes, rays %llu, mean radiance %.5f %.5f %.5f\n", W, H, spp, passes,
@@ -162,7 +174,7 @@ int main(int argc, char** argv)
     if (out) { FILE* fo = fopen(out, "wb"); if (fo) { fwrite(frame, sizeof(float), (size_t)W * H * 4, fo); fclose(fo); } }
     free(frame);
     if (dump) fclose(dump);
-    p_PTDestroy(ctx);
+    if (group) p_PTGroupDestroy(group); else p_PTDestroy(ctx);
     dlclose(lib);
     return 0;
 }

@@ -195,6 +195,38 @@ PT_API int PTSetScene(PTContext* ctx, const PTSceneDesc* scene);
  * rank 0 / worldSize 1 (the default) owns everything. */
 PT_API int PTSetTileOwnership(PTContext* ctx, int rank, int worldSize);
 
+/* Frame assembly for tile sharding: a rank's OWNED tiles packed densely (16 bytes per owned pixel, in the order the kernels
+ * enumerate pixels) instead of a whole zero-padded frame -- 1/worldSize of the bytes of a sum-reduce.  One process per GPU:
+ * pack on every rank, gather the packed buffers on the root (RCCL gather: bench.py), unpack each rank's buffer there.
+ * PTGetOwnedTileSlots: float4 slots of the packed buffer for THIS context's ownership and these params (includes padding of
+ * partially covered blocks; differs by at most one block row between ranks -- size a gather by the maximum).
+ * All buffers are DEVICE pointers on the context's device; the calls are ordered on the context's stream. */
+PT_API int PTGetOwnedTileSlots(PTContext* ctx, const PTFrameParams* params, uint64_t* outFloat4Slots);
+PT_API int PTPackOwnedTiles(PTContext* ctx, const PTFrameParams* params, const void* dFrame, void* dPacked);
+/* Scatters the packed tiles of rank `rank` of `worldSize` into dFrame (any context may unpack any rank's buffer). */
+PT_API int PTUnpackTiles(PTContext* ctx, const PTFrameParams* params, int rank, int worldSize, const void* dPacked, void* dFrame);
+
+/* One process, N devices (a C or C# host without an MPI-style launcher): a group owns one context per device, replicates the
+ * scene, gives context i the tiles of rank i of N, and assembles every pass on the first device: each device packs its tiles,
+ * hipMemcpyPeerAsync moves them over xGMI, the root unpacks.  The per-device passes are enqueued from one host thread per
+ * device.  Progressive accumulation works as on one GPU: every device keeps the history of its own tiles
+ * (PTGroupFlipFrames / PTGroupResetFrames mirror PTFlipFrames / PTResetFrames on all of them).  The same device may be
+ * listed more than once (rehearsal on a one-GPU box).  Frames are bit-identical to the single-GPU frame. */
+typedef struct PTGroup PTGroup;
+PT_API int PTCreateMulti(const int* deviceIndices, int deviceCount, PTGroup** outGroup);
+PT_API int PTGroupDestroy(PTGroup* group);
+PT_API int PTGroupSize(PTGroup* group);
+PT_API PTContext* PTGroupGetContext(PTGroup* group, int index);      /* for PTSetSchedule / PTSetStatsLevel / ... per device */
+PT_API int PTGroupSetScene(PTGroup* group, const PTSceneDesc* scene);
+PT_API int PTGroupRenderPass(PTGroup* group, const PTFrameParams* params);
+PT_API int PTGroupFlipFrames(PTGroup* group);
+PT_API int PTGroupResetFrames(PTGroup* group);
+PT_API int PTGroupSynchronize(PTGroup* group);
+PT_API int PTGroupReadback(PTGroup* group, float* dstRGBA, uint64_t dstFloats);   /* the assembled frame of the last pass */
+PT_API void* PTGroupGetAssembledFrame(PTGroup* group);                            /* its device pointer (first device)    */
+PT_API int PTGroupGetStats(PTGroup* group, PTStats* out);                         /* summed over devices (max for maxStackDepth) */
+PT_API int PTGroupResetStats(PTGroup* group);
+
 /* One progressive pass = one DispatchCompute of the PathTracer kernel (PathTracer.cs:251),
  * using the context's internal ping-pong frames exactly as PathTracer.cs:246-247,268-272:
  * Output = frame[cur], AccumulatedOutput = frame[1-cur]; the caller advances CurrentSample

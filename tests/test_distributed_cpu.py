@@ -1,6 +1,7 @@
 """The N > 1 path on CPU: two processes over gloo shard a frame as interleaved 16x16 blocks, each produces its partial
-frame (here with the oracle standing in for the GPU kernels, which cannot run in this container), and ONE reduce
-onto rank 0 reproduces the single-process frame bit for bit -- the same collective bench.py issues over RCCL."""
+frame (here with the oracle standing in for the GPU kernels, which cannot run in this container), packs its owned tiles,
+and ONE gather onto rank 0 + unpack reproduces the single-process frame bit for bit -- the same exchange bench.py issues
+over RCCL (unity_webgpu_pathtracer_amd/distributed.py gather_frame; pack / unpack here through the numpy mirror of the kernels)."""
 import os
 import socket
 import sys
@@ -37,8 +38,7 @@ def _worker(rank, world, port, out_path):
         p = scenes.frame_params(s, w, h, spp=2, current_sample=2 * k, seed=(0x12345678 + k * 0x9E3779B9) & 0xFFFFFFFF)
         part, _ = pyoracle.render(b, p, accumulated=frames[1 - cur], tile_rank=rank, tile_world=world, threads=1)
         frames[cur] = part
-        t = torch.from_numpy(part.copy())
-        distributed.reduce_frame(t, dst=0)
+        t = distributed.gather_frame(torch.from_numpy(part.copy()), rank, world, dst=0)
         cur = 1 - cur
     if rank == 0:
         np.save(out_path, t.numpy())
@@ -72,3 +72,23 @@ def test_ownership_is_a_partition():
         assert (total == 1).all()
         counts = distributed.owned_pixel_counts(1920, 1080, world)
         assert max(counts) - min(counts) <= 0.02 * 1920 * 1080 / world     # interleaving balances within 2 %
+
+
+def test_pack_unpack_mirror_roundtrip():
+    """The numpy mirror of PTPackOwnedTiles / PTUnpackTiles: every pixel is in exactly one rank's packed buffer, packed sizes
+    are 1/world of the frame (+ block padding), and unpacking all ranks reproduces the frame -- also for sizes that are not
+    multiples of 16 and for more ranks than blocks in a row."""
+    from unity_webgpu_pathtracer_amd import distributed
+    rng = np.random.RandomState(1)
+    for (w, h, world) in ((80, 48, 2), (1920, 1080, 8), (333, 77, 3), (40, 40, 8), (16, 16, 4)):
+        frame = rng.rand(h, w, 4).astype(np.float32)
+        out = np.zeros_like(frame)
+        seen = np.zeros((h, w), np.int32)
+        for r in range(world):
+            px, py, valid = distributed.slot_pixels(w, h, r, world)
+            assert px.size % 256 == 0 and px.size <= distributed.max_packed_slots(w, h, world)
+            m = distributed.ownership_mask(w, h, r, world)
+            assert int(valid.sum()) == int(m.sum()) and m[py[valid], px[valid]].all()
+            np.add.at(seen, (py[valid], px[valid]), 1)
+            distributed.unpack_tiles_numpy(distributed.pack_tiles_numpy(frame * m[..., None], r, world), out, r, world)
+        assert (seen == 1).all() and np.array_equal(out, frame)

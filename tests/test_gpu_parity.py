@@ -277,6 +277,11 @@ def test_plain_c_host(tmp_path, oracle):
         ref, _ = oracle.render(b, p, accumulated=ref)
     assert off == len(raw)
     assert np.array_equal(gpu.view(np.uint32), ref.view(np.uint32))
+    # the same C host, one process driving "two devices" (the same GPU twice) through PTCreateMulti / PTGroup*: same bits
+    out2 = str(tmp_path / "frame_group.f32")
+    subprocess.check_call([os.path.join(root, "host", "pt_host"), "64", "48", "2", "2", out2], cwd=root, stdout=subprocess.DEVNULL,
+                          env=dict(os.environ, PT_HOST_DEVICES="0,0"))
+    assert np.array_equal(np.fromfile(out2, dtype=np.float32).view(np.uint32), gpu.reshape(-1).view(np.uint32))
     # and the C host's scene is the Python generator's Cornell box up to fp32-vs-fp64 rounding of the host-side setup
     assert np.allclose(mats, ref_scene.materials, rtol=1e-5) and np.allclose(verts, ref_scene.vertices)
 

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -327,15 +328,7 @@ int render_to(PTContext* c, const PTFrameParams* hostParams, float4* dOut, const
     if (p->CurrentSample > 0 && !dAcc) return fail(PT_ERR_INVALID_ARG, "CurrentSample > 0 needs an accumulated frame");
     HIP_TRY(hipSetDevice(c->device));
 
-    PTTileMap tm;
-    tm.rank = (uint32_t)c->rank;
-    tm.world = (uint32_t)c->world;
-    uint32_t covW = p->OutputWidth, covH = p->OutputHeight;
-    if (p->DispatchGroupsX && p->DispatchGroupsX * 8u < covW) covW = p->DispatchGroupsX * 8u;
-    if (p->DispatchGroupsY && p->DispatchGroupsY * 8u < covH) covH = p->DispatchGroupsY * 8u;
-    tm.coverW = covW; tm.coverH = covH;
-    tm.blocksX = (covW + 15u) / 16u;
-    tm.blocksY = (covH + 15u) / 16u;
+    const PTTileMap tm = pt_make_tile_map(*p, c->rank, c->world);
 
     EventPair ep = {};
     if (c->profiling) {
@@ -355,7 +348,7 @@ int render_to(PTContext* c, const PTFrameParams* hostParams, float4* dOut, const
         const uint64_t maxIt = (uint64_t)spp * (bounces + 2u) + 4u;
         PTContext::WfSet& set = c->sets[c->nextSet];
         c->nextSet = (c->nextSet + 1u) % PT_WF_SETS;
-        if ((rc = ensure_wavefront(c, set, pt_wf_num_slots(tm), (uint32_t)(maxIt > 65536u ? 65536u : maxIt)))) return rc;
+        if ((rc = ensure_wavefront(c, set, pt_num_slots(tm), (uint32_t)(maxIt > 65536u ? 65536u : maxIt)))) return rc;
         // the launch chain runs on the set's own stream; only its resolve (which reads `accumulated` and writes `output`)
         // is ordered after what the caller has enqueued on the context stream so far, the previous pass included
         HIP_TRY(hipEventRecord(set.callEv, c->stream));
@@ -770,6 +763,253 @@ PT_API int PTSetWavefrontIterations(PTContext* c, int iterations)
 {
     if (!c || iterations < 0) return fail(PT_ERR_INVALID_ARG, "ctx == NULL or iterations < 0");
     c->wfIterations = (uint32_t)iterations;
+    return PT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// tile pack / unpack and the one-process multi-device group (no reference counterpart)
+// ------------------------------------------------------------------------------------------
+PT_API int PTGetOwnedTileSlots(PTContext* c, const PTFrameParams* hostParams, uint64_t* out)
+{
+    if (!c || !out) return fail(PT_ERR_INVALID_ARG, "ctx/out == NULL");
+    PTFrameParams p;
+    int rc = import_params(hostParams, p);
+    if (rc || (rc = validate_params(&p))) return rc;
+    *out = pt_num_slots(pt_make_tile_map(p, c->rank, c->world));
+    return PT_OK;
+}
+
+PT_API int PTPackOwnedTiles(PTContext* c, const PTFrameParams* hostParams, const void* dFrame, void* dPacked)
+{
+    if (!c || !dFrame || !dPacked) return fail(PT_ERR_INVALID_ARG, "ctx/frame/packed == NULL");
+    PTFrameParams p;
+    int rc = import_params(hostParams, p);
+    if (rc || (rc = validate_params(&p))) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(pt_launch_pack_tiles(pt_make_tile_map(p, c->rank, c->world), p.OutputWidth, (const float4*)dFrame, (float4*)dPacked, c->stream));
+    return PT_OK;
+}
+
+PT_API int PTUnpackTiles(PTContext* c, const PTFrameParams* hostParams, int rank, int world, const void* dPacked, void* dFrame)
+{
+    if (!c || !dFrame || !dPacked) return fail(PT_ERR_INVALID_ARG, "ctx/frame/packed == NULL");
+    if (world < 1 || rank < 0 || rank >= world) return fail(PT_ERR_INVALID_ARG, "bad rank/worldSize");
+    PTFrameParams p;
+    int rc = import_params(hostParams, p);
+    if (rc || (rc = validate_params(&p))) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(pt_launch_unpack_tiles(pt_make_tile_map(p, rank, world), p.OutputWidth, (const float4*)dPacked, (float4*)dFrame, c->stream));
+    return PT_OK;
+}
+
+} // extern "C"
+
+struct PTGroup {
+    std::vector<PTContext*> ctx;
+    std::vector<float4*> packed;        // on device i: its owned tiles, dense
+    std::vector<float4*> staged;        // on the root device: the same, after the peer copy (staged[0] == packed[0])
+    std::vector<hipEvent_t> arrived;    // recorded on ctx[i]->stream after the peer copy
+    std::vector<size_t> packedBytes;
+    float4* assembled = nullptr;
+    uint32_t frameW = 0, frameH = 0;
+};
+
+namespace {
+
+// runs fn(i) for every device of the group, device 0 on the calling thread and the others on one thread each (a pass is
+// ~160 launches per device: enqueued serially, eight devices would be host-bound); the first error is re-raised here
+template <class F>
+int for_each_device(PTGroup* g, F fn)
+{
+    const size_t n = g->ctx.size();
+    std::vector<int> rcs(n, PT_OK);
+    std::vector<std::string> msgs(n);
+    std::vector<std::thread> workers;
+    for (size_t i = 1; i < n; ++i)
+        workers.emplace_back([&, i] { rcs[i] = fn((int)i); if (rcs[i]) msgs[i] = g_lastError; });
+    rcs[0] = fn(0);
+    if (rcs[0]) msgs[0] = g_lastError;
+    for (auto& w : workers) w.join();
+    for (size_t i = 0; i < n; ++i)
+        if (rcs[i]) return fail(rcs[i], "device " + std::to_string(g->ctx[i]->device) + " (rank " + std::to_string(i) + "): " + msgs[i]);
+    return PT_OK;
+}
+
+int group_ensure_buffers(PTGroup* g, const PTFrameParams& p)
+{
+    PTContext* root = g->ctx[0];
+    const size_t frameBytes = (size_t)p.OutputWidth * p.OutputHeight * sizeof(float4);
+    if (!g->assembled || g->frameW != p.OutputWidth || g->frameH != p.OutputHeight) {
+        HIP_TRY(hipSetDevice(root->device));
+        if (g->assembled) { HIP_TRY(hipStreamSynchronize(root->stream)); hipFree(g->assembled); g->assembled = nullptr; }
+        HIP_TRY(hipMalloc((void**)&g->assembled, frameBytes));
+        HIP_TRY(hipMemsetAsync(g->assembled, 0, frameBytes, root->stream));
+        g->frameW = p.OutputWidth; g->frameH = p.OutputHeight;
+    }
+    for (size_t i = 0; i < g->ctx.size(); ++i) {
+        const size_t need = (size_t)pt_num_slots(pt_make_tile_map(p, (int)i, (int)g->ctx.size())) * sizeof(float4);
+        if (g->packedBytes[i] >= need) continue;
+        PTContext* c = g->ctx[i];
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (g->packed[i]) hipFree(g->packed[i]);
+        HIP_TRY(hipMalloc((void**)&g->packed[i], need));
+        if (i > 0) {
+            HIP_TRY(hipSetDevice(root->device));
+            HIP_TRY(hipStreamSynchronize(root->stream));
+            if (g->staged[i]) hipFree(g->staged[i]);
+            HIP_TRY(hipMalloc((void**)&g->staged[i], need));
+        } else g->staged[0] = g->packed[0];
+        g->packedBytes[i] = need;
+    }
+    return PT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+PT_API int PTCreateMulti(const int* devices, int n, PTGroup** out)
+{
+    if (!out) return fail(PT_ERR_INVALID_ARG, "outGroup == NULL");
+    *out = nullptr;
+    if (!devices || n < 1 || n > 64) return fail(PT_ERR_INVALID_ARG, "deviceIndices == NULL or deviceCount outside 1..64");
+    PTGroup* g = new PTGroup();
+    for (int i = 0; i < n; ++i) {
+        PTContext* c = nullptr;
+        int rc = PTCreate(devices[i], &c);
+        if (rc == PT_OK) rc = PTSetTileOwnership(c, i, n);
+        if (rc != PT_OK) {
+            const std::string msg = g_lastError;
+            if (c) PTDestroy(c);
+            for (PTContext* d : g->ctx) PTDestroy(d);
+            delete g;
+            return fail(rc, msg);
+        }
+        g->ctx.push_back(c);
+    }
+    g->packed.assign(n, nullptr);
+    g->staged.assign(n, nullptr);
+    g->packedBytes.assign(n, 0);
+    g->arrived.assign(n, nullptr);
+    for (int i = 0; i < n; ++i) {
+        hipSetDevice(g->ctx[i]->device);
+        if (hipEventCreateWithFlags(&g->arrived[i], hipEventDisableTiming) != hipSuccess) { PTGroupDestroy(g); return fail(PT_ERR_HIP, "hipEventCreate failed"); }
+        // direct xGMI copies into the root's staging buffers; "already enabled" / "not supported" leave the staged path
+        if (g->ctx[i]->device != g->ctx[0]->device) { (void)hipDeviceEnablePeerAccess(g->ctx[0]->device, 0); (void)hipGetLastError(); }
+    }
+    *out = g;
+    return PT_OK;
+}
+
+PT_API int PTGroupDestroy(PTGroup* g)
+{
+    if (!g) return PT_OK;
+    for (size_t i = 0; i < g->ctx.size(); ++i) {
+        PTContext* c = g->ctx[i];
+        hipSetDevice(c->device);
+        hipStreamSynchronize(c->stream);
+        if (g->packed[i]) hipFree(g->packed[i]);
+        if (i > 0 && g->staged[i]) { hipSetDevice(g->ctx[0]->device); hipFree(g->staged[i]); }
+        if (g->arrived[i]) hipEventDestroy(g->arrived[i]);
+    }
+    if (g->assembled) { hipSetDevice(g->ctx[0]->device); hipStreamSynchronize(g->ctx[0]->stream); hipFree(g->assembled); }
+    for (PTContext* c : g->ctx) PTDestroy(c);
+    delete g;
+    return PT_OK;
+}
+
+PT_API int PTGroupSize(PTGroup* g) { return g ? (int)g->ctx.size() : fail(PT_ERR_INVALID_ARG, "group == NULL"); }
+PT_API PTContext* PTGroupGetContext(PTGroup* g, int i) { return (g && i >= 0 && i < (int)g->ctx.size()) ? g->ctx[i] : nullptr; }
+
+PT_API int PTGroupSetScene(PTGroup* g, const PTSceneDesc* scene)
+{
+    if (!g) return fail(PT_ERR_INVALID_ARG, "group == NULL");
+    return for_each_device(g, [&](int i) { return PTSetScene(g->ctx[i], scene); });
+}
+
+PT_API int PTGroupRenderPass(PTGroup* g, const PTFrameParams* hostParams)
+{
+    if (!g) return fail(PT_ERR_INVALID_ARG, "group == NULL");
+    PTFrameParams p;
+    int rc = import_params(hostParams, p);
+    if (rc || (rc = validate_params(&p))) return rc;
+    if ((rc = group_ensure_buffers(g, p))) return rc;
+    PTContext* root = g->ctx[0];
+    const int world = (int)g->ctx.size();
+    rc = for_each_device(g, [&](int i) -> int {
+        PTContext* c = g->ctx[i];
+        int r = PTRenderPass(c, &p);                                   // owned tiles into the device's own ping-pong frames
+        if (r) return r;
+        HIP_TRY(pt_launch_pack_tiles(pt_make_tile_map(p, i, world), p.OutputWidth, c->frames[c->cur], g->packed[i], c->stream));
+        if (i > 0) HIP_TRY(hipMemcpyPeerAsync(g->staged[i], root->device, g->packed[i], c->device, g->packedBytes[i], c->stream));
+        HIP_TRY(hipEventRecord(g->arrived[i], c->stream));
+        return PT_OK;
+    });
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(root->device));
+    for (int i = 0; i < world; ++i) {
+        if (i > 0) HIP_TRY(hipStreamWaitEvent(root->stream, g->arrived[i], 0));
+        HIP_TRY(pt_launch_unpack_tiles(pt_make_tile_map(p, i, world), p.OutputWidth, g->staged[i], g->assembled, root->stream));
+    }
+    return PT_OK;
+}
+
+PT_API int PTGroupFlipFrames(PTGroup* g)
+{
+    if (!g) return fail(PT_ERR_INVALID_ARG, "group == NULL");
+    for (PTContext* c : g->ctx) PTFlipFrames(c);
+    return PT_OK;
+}
+
+PT_API int PTGroupResetFrames(PTGroup* g)
+{
+    if (!g) return fail(PT_ERR_INVALID_ARG, "group == NULL");
+    for (PTContext* c : g->ctx) PTResetFrames(c);
+    return PT_OK;
+}
+
+PT_API int PTGroupSynchronize(PTGroup* g)
+{
+    if (!g) return fail(PT_ERR_INVALID_ARG, "group == NULL");
+    for (size_t i = g->ctx.size(); i-- > 0;) { int rc = PTSynchronize(g->ctx[i]); if (rc) return rc; }   // the root last: it waits for the others
+    return PT_OK;
+}
+
+PT_API int PTGroupReadback(PTGroup* g, float* dst, uint64_t dstFloats)
+{
+    if (!g || !dst) return fail(PT_ERR_INVALID_ARG, "group/dst == NULL");
+    if (!g->assembled) return fail(PT_ERR_INVALID_ARG, "no frame rendered yet");
+    const uint64_t need = (uint64_t)g->frameW * g->frameH * 4;
+    if (dstFloats < need) return fail(PT_ERR_INVALID_ARG, "destination too small");
+    PTContext* root = g->ctx[0];
+    HIP_TRY(hipSetDevice(root->device));
+    HIP_TRY(hipMemcpyAsync(dst, g->assembled, need * sizeof(float), hipMemcpyDeviceToHost, root->stream));
+    HIP_TRY(hipStreamSynchronize(root->stream));
+    return PT_OK;
+}
+
+PT_API void* PTGroupGetAssembledFrame(PTGroup* g) { return g ? (void*)g->assembled : nullptr; }
+
+PT_API int PTGroupGetStats(PTGroup* g, PTStats* out)
+{
+    if (!g || !out) return fail(PT_ERR_INVALID_ARG, "group/out == NULL");
+    uint64_t acc[16] = {};
+    for (PTContext* c : g->ctx) {
+        PTStats st;
+        int rc = PTGetStats(c, &st);
+        if (rc) return rc;
+        const uint64_t* v = (const uint64_t*)&st;
+        for (int k = 0; k < 16; ++k) { if (k == 12) acc[k] = v[k] > acc[k] ? v[k] : acc[k]; else acc[k] += v[k]; }
+    }
+    memcpy(out, acc, sizeof(PTStats));
+    return PT_OK;
+}
+
+PT_API int PTGroupResetStats(PTGroup* g)
+{
+    if (!g) return fail(PT_ERR_INVALID_ARG, "group == NULL");
+    for (PTContext* c : g->ctx) { int rc = PTResetStats(c); if (rc) return rc; }
     return PT_OK;
 }
 

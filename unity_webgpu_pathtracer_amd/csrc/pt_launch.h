@@ -11,6 +11,43 @@ struct PTTileMap {
     uint32_t coverW, coverH;       // pixels with x < coverW && y < coverH are rendered
 };
 
+// slot <-> pixel: owned 16x16 blocks in row-major order of (block row, k-th owned block of that row), 256 slots per block,
+// one wave per 8x8 tile.  Shared by the megakernel, the wavefront schedules and the tile pack / unpack of the multi-GPU gather.
+__host__ __device__ inline uint32_t pt_num_slots(const PTTileMap& tm)
+{
+    const uint32_t bpr = (tm.blocksX + tm.world - 1u) / tm.world;       // owned blocks per block-row (upper bound)
+    return bpr * tm.blocksY * 256u;
+}
+__host__ __device__ inline bool pt_slot_to_pixel(const PTTileMap& tm, uint32_t slot, uint32_t& px, uint32_t& py)
+{
+    const uint32_t bpr = (tm.blocksX + tm.world - 1u) / tm.world;
+    const uint32_t block = slot >> 8, tid = slot & 255u;
+    const uint32_t by = block / bpr, k = block % bpr;
+    const uint32_t first = (uint32_t)(((int)tm.rank - (int)(by % tm.world) + (int)tm.world) % (int)tm.world);
+    const uint32_t bx = first + k * tm.world;
+    const uint32_t wave = tid >> 6, lane = tid & 63u;
+    px = bx * 16u + (wave & 1u) * 8u + (lane & 7u);
+    py = by * 16u + (wave >> 1) * 8u + (lane >> 3);
+    return bx < tm.blocksX && by < tm.blocksY && px < tm.coverW && py < tm.coverH;
+}
+inline PTTileMap pt_make_tile_map(const PTFrameParams& p, int rank, int world)
+{
+    PTTileMap tm;
+    tm.rank = (uint32_t)rank;
+    tm.world = (uint32_t)world;
+    uint32_t covW = p.OutputWidth, covH = p.OutputHeight;
+    if (p.DispatchGroupsX && p.DispatchGroupsX * 8u < covW) covW = p.DispatchGroupsX * 8u;
+    if (p.DispatchGroupsY && p.DispatchGroupsY * 8u < covH) covH = p.DispatchGroupsY * 8u;
+    tm.coverW = covW; tm.coverH = covH;
+    tm.blocksX = (covW + 15u) / 16u;
+    tm.blocksY = (covH + 15u) / 16u;
+    return tm;
+}
+
+// multi-GPU frame assembly (pt_tiles.hip): packed[slot] = frame[pixel(slot)] and back
+hipError_t pt_launch_pack_tiles(const PTTileMap& tm, uint32_t frameWidth, const float4* frame, float4* packed, hipStream_t stream);
+hipError_t pt_launch_unpack_tiles(const PTTileMap& tm, uint32_t frameWidth, const float4* packed, float4* frame, hipStream_t stream);
+
 hipError_t pt_launch_megakernel(const DScene& S, const PTFrameParams& P, const float4* accumulated, float4* output,
                                 const PTTileMap& tm, unsigned long long* gstats, bool fullStats, hipStream_t stream);
 
@@ -44,7 +81,6 @@ struct PTWfBuffers {
     uint32_t residentWaves;     // waves the device holds at the trace kernel's occupancy (CUs x 4 SIMDs x 8)
 };
 
-uint32_t pt_wf_num_slots(const PTTileMap& tm);
 hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const float4* accumulated, float4* output,
                                const PTTileMap& tm, const PTWfBuffers& B, unsigned long long* gstats, bool fullStats,
                                hipStream_t stream, hipEvent_t orderAfter, bool zeroOutputFirst,

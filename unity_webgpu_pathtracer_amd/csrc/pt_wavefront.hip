@@ -37,20 +37,6 @@ PT_DEV bool fl_pending(uint32_t f) { return (f >> 2) & 1u; }
 PT_DEV uint32_t fl_env(uint32_t f) { return (f >> 3) & 3u; }
 PT_DEV uint32_t fl_light(uint32_t f) { return (f >> 5) & 1u; }
 
-// slot -> pixel: the megakernel's mapping (16x16 blocks, one wave per 8x8 tile, interleaved block ownership)
-PT_DEV bool slot_to_pixel(const PTTileMap& tm, uint32_t slot, uint32_t& px, uint32_t& py)
-{
-    const uint32_t bpr = (tm.blocksX + tm.world - 1u) / tm.world;       // owned blocks per block-row (upper bound)
-    const uint32_t block = slot >> 8, tid = slot & 255u;
-    const uint32_t by = block / bpr, k = block % bpr;
-    const uint32_t first = (uint32_t)(((int)tm.rank - (int)(by % tm.world) + (int)tm.world) % (int)tm.world);
-    const uint32_t bx = first + k * tm.world;
-    const uint32_t wave = tid >> 6, lane = tid & 63u;
-    px = bx * 16u + (wave & 1u) * 8u + (lane & 7u);
-    py = by * 16u + (wave >> 1) * 8u + (lane >> 3);
-    return bx < tm.blocksX && by < tm.blocksY && px < tm.coverW && py < tm.coverH;
-}
-
 PT_DEV float4 f4(v3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
 PT_DEV v3 xyz(float4 v) { return mk3(v.x, v.y, v.z); }
 
@@ -104,7 +90,7 @@ __global__ __launch_bounds__(256) void pt_wf_init(PTFrameParams P, PTTileMap tm,
     if (slot >= B.numSlots) return;
     uint32_t px, py;
     Counters cn = {};
-    if (!slot_to_pixel(tm, slot, px, py)) B.flags[slot] = PS_DONE;
+    if (!pt_slot_to_pixel(tm, slot, px, py)) B.flags[slot] = PS_DONE;
     else {
         PathRegs r;
         path_init(P, px, py, py * P.OutputWidth + px, r, cn);
@@ -564,7 +550,7 @@ PT_DEV bool shade_slot(const DScene& S, const PTFrameParams& P, const PTTileMap&
                        Counters& cn)
 {
     uint32_t px, py;
-    slot_to_pixel(tm, slot, px, py);
+    pt_slot_to_pixel(tm, slot, px, py);
     PathRegs r;
     load_path(B, slot, f, r);
     bool occEnv = false, occLight = false;
@@ -622,7 +608,7 @@ __global__ __launch_bounds__(256, 2) void pt_wf_cleanup(DScene S, PTFrameParams 
     if (__any(fl_state(f) != PS_DONE)) {
         if (fl_state(f) != PS_DONE) {
             uint32_t px, py;
-            slot_to_pixel(tm, slot, px, py);
+            pt_slot_to_pixel(tm, slot, px, py);
             PathRegs r;
             load_path(B, slot, f, r);
             if (r.hasPending) {
@@ -672,7 +658,7 @@ __global__ __launch_bounds__(256) void pt_wf_resolve(PTFrameParams P, PTTileMap 
     const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
     uint32_t px, py;
     Counters cn = {};
-    if (slot < B.numSlots && slot_to_pixel(tm, slot, px, py)) {
+    if (slot < B.numSlots && pt_slot_to_pixel(tm, slot, px, py)) {
         const uint32_t pixelIndex = py * P.OutputWidth + px;
         const uint32_t numSamples = P.SamplesPerPass > 1 ? (uint32_t)P.SamplesPerPass : 1u;
         const float fSamples = (float)numSamples;
@@ -719,11 +705,6 @@ __global__ __launch_bounds__(256) void pt_wf_fold_rows(unsigned long long* rows,
 
 } // namespace
 
-uint32_t pt_wf_num_slots(const PTTileMap& tm)
-{
-    const uint32_t bpr = (tm.blocksX + tm.world - 1u) / tm.world;
-    return bpr * tm.blocksY * 256u;
-}
 
 // One pass = a fixed sequence of launches on `stream`, no host synchronisation (see the file header).
 // `orderAfter` (may be null) is the event of the previous pass's resolve: this pass's resolve reads that pass's output as

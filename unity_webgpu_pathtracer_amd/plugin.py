@@ -68,6 +68,14 @@ def load_library():
         "PTPresent": (i32, [vp, C.POINTER(abi.PTPresentParams), vp, vp]),
         "PTPresentToHost": (i32, [vp, C.POINTER(abi.PTPresentParams), vp, C.c_uint64]),
         "PTSetSchedule": (i32, [vp, i32]), "PTGetSchedule": (i32, [vp]), "PTSetWavefrontIterations": (i32, [vp, i32]),
+        "PTGetOwnedTileSlots": (i32, [vp, C.POINTER(abi.PTFrameParams), C.POINTER(C.c_uint64)]),
+        "PTPackOwnedTiles": (i32, [vp, C.POINTER(abi.PTFrameParams), vp, vp]),
+        "PTUnpackTiles": (i32, [vp, C.POINTER(abi.PTFrameParams), i32, i32, vp, vp]),
+        "PTCreateMulti": (i32, [C.POINTER(i32), i32, C.POINTER(vp)]), "PTGroupDestroy": (i32, [vp]), "PTGroupSize": (i32, [vp]),
+        "PTGroupGetContext": (vp, [vp, i32]), "PTGroupSetScene": (i32, [vp, C.POINTER(abi.PTSceneDesc)]),
+        "PTGroupRenderPass": (i32, [vp, C.POINTER(abi.PTFrameParams)]), "PTGroupFlipFrames": (i32, [vp]), "PTGroupResetFrames": (i32, [vp]),
+        "PTGroupSynchronize": (i32, [vp]), "PTGroupReadback": (i32, [vp, vp, C.c_uint64]), "PTGroupGetAssembledFrame": (vp, [vp]),
+        "PTGroupGetStats": (i32, [vp, C.POINTER(abi.PTStats)]), "PTGroupResetStats": (i32, [vp]),
         "PTGetLastError": (C.c_char_p, []), "PTGetVersion": (i32, []),
     }
     for name, (res, args) in sig.items():
@@ -84,6 +92,9 @@ EXPORTED_SYMBOLS = [
     "PTCreate", "PTDestroy", "PTSetScene", "PTSetTileOwnership", "PTRenderPass", "PTFlipFrames", "PTResetFrames",
     "PTRenderPassTo", "PTSynchronize", "PTReadback", "PTGetFramePointer", "PTGetStream", "PTSetStatsLevel", "PTGetStats",
     "PTResetStats", "PTSetProfiling", "PTGetTimings", "PTResetTimings", "PTProcessMeshes", "PTCopyTextureData", "PTPresent", "PTPresentToHost", "PTSetSchedule", "PTGetSchedule", "PTSetWavefrontIterations",
+    "PTGetOwnedTileSlots", "PTPackOwnedTiles", "PTUnpackTiles", "PTCreateMulti", "PTGroupDestroy", "PTGroupSize", "PTGroupGetContext",
+    "PTGroupSetScene", "PTGroupRenderPass", "PTGroupFlipFrames", "PTGroupResetFrames", "PTGroupSynchronize", "PTGroupReadback",
+    "PTGroupGetAssembledFrame", "PTGroupGetStats", "PTGroupResetStats",
     "PTGetLastError", "PTGetVersion",
 ]
 
