@@ -57,6 +57,16 @@ PT_API int   GetCWBVHTrisSize(int index);
 /* plugin.cpp:72-86.  Borrowed pointers, valid until DestroyBVH(index). */
 PT_API int   GetCWBVHData(int index, PTFloat4** bvhNodes, PTFloat4** bvhTris);
 
+/* No reference counterpart: the same CWBVH format built ON the MI355X -- LBVH (63-bit Morton keys, radix
+ * sort, Karras radix tree), greedy surface-area collapse to 8-wide, CWBVH encode, all in HIP kernels.  The tree differs from
+ * BuildBVH's binned-SAH tree (so the bytes differ), every ray finds the same closest hit.  The handle lives in BuildBVH's
+ * table: GetCWBVHNodesSize / GetCWBVHTrisSize / GetCWBVHData / IsBVHReady / DestroyBVH apply.  Returns -1 on degenerate input
+ * or when deviceIndex is not a HIP device (PTGetBVHBuildError() has the text); there is no CPU fallback behind this entry. */
+PT_API int   PTBuildBVHDevice(int deviceIndex, const PTFloat4* vertices, int triangleCount);
+PT_API const char* PTGetBVHBuildError(void);
+/* Build time of a handle in milliseconds: host wall time of BuildBVH, device time (kernels only) of PTBuildBVHDevice. */
+PT_API double PTGetBVHBuildMs(int index);
+
 /* plugin.cpp:111-118.  2-wide SAH BVH over the instances' world AABBs, Aila-Laine layout. */
 PT_API int   BuildTLAS(const PTBlasInstance* instances, int instanceCount);
 PT_API void  DestroyTLAS(int index);                                     /* plugin.cpp:120-130 */

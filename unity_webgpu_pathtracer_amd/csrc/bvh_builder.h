@@ -1,6 +1,7 @@
 // bvh_builder.h — acceleration-structure builders behind BuildBVH / BuildTLAS (see bvh_builder.cpp).
 #pragma once
 #include <stdint.h>
+#include <string>
 #include <vector>
 #include "ptmi_layouts.h"
 
@@ -38,7 +39,11 @@ public:
     std::vector<PTFloat4> nodeData;     // usedBlocks float4s are valid (5 per node)
     std::vector<PTFloat4> triData;      // triCount * 3 float4s
     uint32_t usedBlocks = 0, triCount = 0;
+    double buildMs = 0.0;               // BuildBVH: host wall time of build(); PTBuildBVHDevice: device time of the kernels
 };
+
+// bvh_builder_gpu.hip: LBVH + 8-wide collapse + CWBVH encode on the MI355X (same output format, a different tree)
+bool build_cwbvh_device(int device, const PTFloat4* verts, uint32_t triCount, Cwbvh& out, double* deviceMs, std::string& err);
 
 // Two-level top: 2-wide BVH over instance AABBs in the Aila-Laine layout (PTTlasNode).
 class Tlas {

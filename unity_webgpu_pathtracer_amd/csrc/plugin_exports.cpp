@@ -5,8 +5,10 @@
 // table (plugin.cpp:8-21, 90-103), Destroy* frees and nulls the slot, invalid handles read as 0 / NULL.
 // Differences, all on the safe side: degenerate input returns -1 instead of exit(1)
 // (tiny_bvh.h:1615-1618), and "bool" results are full-width ints.
+#include <chrono>
 #include <cstddef>
 #include <deque>
+#include <string>
 #include "bvh_builder.h"
 #include "ptmi_plugin.h"
 
@@ -37,8 +39,28 @@ PT_API int BuildBVH(const PTFloat4* vertices, int triangleCount)
 {
     if (!vertices || triangleCount <= 0) return -1;
     ptbvh::Cwbvh* bvh = new ptbvh::Cwbvh();
+    const auto t0 = std::chrono::steady_clock::now();
     if (!bvh->build(vertices, (uint32_t)triangleCount)) { delete bvh; return -1; }
+    bvh->buildMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return add_slot(g_bvhs, bvh);
+}
+
+// The builder that runs on the MI355X (bvh_builder_gpu.hip).  Same handle table as BuildBVH: every Get* / DestroyBVH export
+// works on the handle.  -1 on degenerate input or when there is no such HIP device (no CPU fallback: BuildBVH is the CPU path).
+namespace { std::string g_buildError; }
+PT_API int PTBuildBVHDevice(int deviceIndex, const PTFloat4* vertices, int triangleCount)
+{
+    if (!vertices || triangleCount <= 0) { g_buildError = "vertices == NULL or triangleCount <= 0"; return -1; }
+    ptbvh::Cwbvh* bvh = new ptbvh::Cwbvh();
+    if (!ptbvh::build_cwbvh_device(deviceIndex, vertices, (uint32_t)triangleCount, *bvh, &bvh->buildMs, g_buildError)) { delete bvh; return -1; }
+    g_buildError.clear();
+    return add_slot(g_bvhs, bvh);
+}
+PT_API const char* PTGetBVHBuildError(void) { return g_buildError.c_str(); }
+PT_API double PTGetBVHBuildMs(int index)
+{
+    ptbvh::Cwbvh* b = get_slot(g_bvhs, index);
+    return b ? b->buildMs : -1.0;
 }
 PT_API void DestroyBVH(int index) { free_slot(g_bvhs, index); }
 PT_API int IsBVHReady(int index) { return get_slot(g_bvhs, index) != nullptr; }

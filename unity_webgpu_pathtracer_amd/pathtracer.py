@@ -20,8 +20,11 @@ from .scenes import Scene, frame_params
 class BVHScene:
     """Scene buffers as BVHScene.cs holds them, uploaded into HBM by PTSetScene."""
 
-    def __init__(self, scene: Scene):
+    def __init__(self, scene: Scene, build_device: int = None):
+        """build_device = None: BuildBVH (the reference's CPU builder, byte-identical); k: PTBuildBVHDevice on HIP device k."""
         self.scene = scene
+        self.build_device = build_device
+        self.build_ms = {}
         self.tlas_data = None
         self.tlas_index_offset = 0
         self.gpu_instances = None
@@ -29,7 +32,7 @@ class BVHScene:
             self._build_two_level(scene)
         else:
             # BVHScene.cs:629-659: BuildBVH over the world-space triangle soup, copy node/triangle bytes out
-            self.bvh_nodes, self.bvh_tris = plugin.build_cwbvh(scene.vertices)
+            self.bvh_nodes, self.bvh_tris = plugin.build_cwbvh(scene.vertices, device=build_device, timing=self.build_ms)
         self.tri_attrs = np.ascontiguousarray(scene.tri_attrs)
         self.materials = np.ascontiguousarray(scene.materials, dtype=np.float32)
         self.lights = np.ascontiguousarray(scene.lights, dtype=np.float32)
@@ -43,7 +46,7 @@ class BVHScene:
         nodes, tris, node_off, tri_off = [], [], [], []
         n_off = t_off = 0
         for t0, n in scene.mesh_ranges:
-            nb, tb = plugin.build_cwbvh(scene.vertices[t0 * 3:(t0 + n) * 3])
+            nb, tb = plugin.build_cwbvh(scene.vertices[t0 * 3:(t0 + n) * 3], device=self.build_device)
             nodes.append(nb)
             tris.append(tb)
             node_off.append(n_off)
@@ -110,7 +113,8 @@ class PathTracer:
     def __init__(self, scene: Scene, device: int = 0, width: int = 256, height: int = 256,
                  samplesPerPass: int = 1, maxSamples: int = 100000, maxRayBounces: int = 4,
                  useRussianRoulette: bool = True, fireflyFilter: bool = False, maxFireflyLuminance: float = 10.0,
-                 rank: int = 0, world_size: int = 1, reference_dispatch: bool = False, schedule: int = None):
+                 rank: int = 0, world_size: int = 1, reference_dispatch: bool = False, schedule: int = None,
+                 build_device: int = None):
         self.lib = plugin.load_library()
         self.scene = scene
         self.width, self.height = width, height
@@ -130,7 +134,7 @@ class PathTracer:
         ctx = C.c_void_p()
         plugin.check(self.lib.PTCreate(device, C.byref(ctx)))
         self.ctx = ctx
-        self._bvhScene = BVHScene(scene)
+        self._bvhScene = BVHScene(scene, build_device=build_device)
         self._bvhScene.PrepareShader(self.ctx)
         if world_size > 1:
             plugin.check(self.lib.PTSetTileOwnership(self.ctx, rank, world_size))

@@ -50,6 +50,7 @@ def load_library():
         "GetBVHPtr": (vp, [i32]), "GetBVH": (vp, [i32]),
         "GetCWBVHNodesSize": (i32, [i32]), "GetCWBVHTrisSize": (i32, [i32]),
         "GetCWBVHData": (i32, [i32, C.POINTER(vp), C.POINTER(vp)]),
+        "PTBuildBVHDevice": (i32, [i32, vp, i32]), "PTGetBVHBuildError": (C.c_char_p, []), "PTGetBVHBuildMs": (C.c_double, [i32]),
         "BuildTLAS": (i32, [vp, i32]), "DestroyTLAS": (None, [i32]), "IsTLASReady": (i32, [i32]),
         "GetTLASNodesSize": (i32, [i32]), "GetTLASData": (i32, [i32, C.POINTER(vp), C.POINTER(vp)]),
         # Part 2 (render)
@@ -88,6 +89,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = [
     "BuildBVH", "DestroyBVH", "IsBVHReady", "GetBVHPtr", "GetBVH", "GetCWBVHNodesSize", "GetCWBVHTrisSize", "GetCWBVHData",
+    "PTBuildBVHDevice", "PTGetBVHBuildError", "PTGetBVHBuildMs",
     "BuildTLAS", "DestroyTLAS", "IsTLASReady", "GetTLASNodesSize", "GetTLASData",
     "PTCreate", "PTDestroy", "PTSetScene", "PTSetTileOwnership", "PTRenderPass", "PTFlipFrames", "PTResetFrames",
     "PTRenderPassTo", "PTSynchronize", "PTReadback", "PTGetFramePointer", "PTGetStream", "PTSetStatsLevel", "PTGetStats",
@@ -168,15 +170,25 @@ class TinyBVH:
         return bool(ok), n.value, i.value
 
 
-def build_cwbvh(vertices: np.ndarray):
+def build_cwbvh(vertices: np.ndarray, device: int = None, timing: dict = None):
     """What BVHScene.OnCompleteReadback does with the plugin (BVHScene.cs:629-659): BuildBVH, read the sizes,
     fetch the borrowed pointers, copy the bytes out (Utilities.UploadFromPointer), DestroyBVH.
+    device = None: BuildBVH (CPU, byte-identical to the reference plugin); device = k: PTBuildBVHDevice on HIP device k
+    (same format, a different tree).  timing (optional dict) receives {"build_ms": ...}.
     Returns (nodes uint8[], tris uint8[])."""
     v = np.ascontiguousarray(vertices, dtype=np.float32)
     assert v.ndim == 2 and v.shape[1] == 4 and v.shape[0] % 3 == 0
-    h = TinyBVH.BuildBVH(v.ctypes.data_as(C.c_void_p), v.shape[0] // 3)
-    if h < 0:
-        raise PluginError(h, "BuildBVH failed")
+    lib = load_library()
+    if device is None:
+        h = TinyBVH.BuildBVH(v.ctypes.data_as(C.c_void_p), v.shape[0] // 3)
+        if h < 0:
+            raise PluginError(h, "BuildBVH failed")
+    else:
+        h = lib.PTBuildBVHDevice(device, v.ctypes.data_as(C.c_void_p), v.shape[0] // 3)
+        if h < 0:
+            raise PluginError(h, "PTBuildBVHDevice failed: " + lib.PTGetBVHBuildError().decode())
+    if timing is not None:
+        timing["build_ms"] = float(lib.PTGetBVHBuildMs(h))
     try:
         nb, tb = TinyBVH.GetCWBVHNodesSize(h), TinyBVH.GetCWBVHTrisSize(h)
         ok, pn, pt = TinyBVH.GetCWBVHData(h)
