@@ -398,6 +398,223 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(
 }
 
 // ------------------------------------------------------------------------------------------
+// HAS_TLAS through the refill scheduler (util/tlas.hlsl:129-332).  The two-level walk of a ray is cut so that the hot loop of
+// the wave contains ONE kind of step, the CWBVH iteration of the instance a lane is inside (ray_step with the instance's
+// node / triangle / attribute offsets and the tmin = 0 triangle test); whenever a lane's instance is finished it runs the
+// instance epilogue (world-space position and distance, tlas.hlsl:208-229) and walks the 2-wide TLAS -- a short, rarely taken
+// loop -- to the next instance whose box it hits.  Per lane: the BLAS stack in LDS (8 entries, deeper ones in the HBM slab) plus
+// a second, narrow LDS stack for TLAS node indices; the world-space ray is re-read from the slot arrays when an instance is
+// entered.  Same per-ray operation order as traverse_tlas, so frames and all counters stay bit-identical.
+// ------------------------------------------------------------------------------------------
+#define PT_WF_TLAS_LDS_STACK 8u
+
+#ifndef PT_WF_TLAS_MIN_WAVES
+#define PT_WF_TLAS_MIN_WAVES 5
+#endif
+template <bool STATS>
+__global__ __launch_bounds__(64, PT_WF_TLAS_MIN_WAVES) void pt_wf_trace_refill_tlas(DScene S, PTWfBuffers B)
+{
+    __shared__ uint2 s_stack[PT_WF_LDS_STACK][64];
+    __shared__ uint32_t s_tstack[PT_WF_TLAS_LDS_STACK][64];
+    __shared__ uint32_t s_xchg[64];
+    __shared__ uint32_t s_gw;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t gw = blockIdx.x;
+    const uint32_t slotBase = gw * PT_WF_RANGE;
+    const unsigned long long ltMask = (1ull << lane) - 1ull;
+    volatile uint32_t* xchg = s_xchg;
+    volatile uint32_t* tlds = &s_tstack[0][lane];
+    if (lane == 0u) s_gw = gw;
+    const uint32_t nItems = 3u * PT_WF_RANGE;
+    const float* T = S.tlas;
+
+    Counters cn = {};
+    TravStackT<PT_WF_LDS_STACK, true> st;
+    st.lds = &s_stack[0][lane];
+    st.stride = 64u;
+    st.gbase = B.stackSpill;
+    st.gwave = PT_LDS_WORD(s_gw);
+    RayState rs;
+    rs.sp = 0u; rs.anyHit = false; rs.overflow = false;
+    bool have = false, inBlas = false, needPop = false, hitFound = false;
+    uint32_t mySlot = 0u, myKind = 0u, cursor = 0u;
+    v3 O = mk3(0.0f), rD = mk3(0.0f);
+    uint32_t nodeIndex = 0u, tsp = 0u, nextInst = 0u, instLeft = 0u;
+    uint32_t nodeOffset = 0u, triOffset = 0u, attrOffset = 0u, instIndex = 0u;
+
+    auto tpush = [&](uint32_t v) {
+        if (tsp < PT_WF_TLAS_LDS_STACK) tlds[tsp * 64u] = v;
+        else if (tsp < PT_BVH_STACK_SIZE) B.tlasSpill[spill_row(PT_LDS_WORD(s_gw)) * (PT_BVH_STACK_SIZE - PT_WF_TLAS_LDS_STACK) + (tsp - PT_WF_TLAS_LDS_STACK)] = v;
+        tsp++;
+    };
+    auto tpop = [&]() -> uint32_t {
+        --tsp;
+        if (tsp < PT_WF_TLAS_LDS_STACK) return tlds[tsp * 64u];
+        if (tsp < PT_BVH_STACK_SIZE) return B.tlasSpill[spill_row(PT_LDS_WORD(s_gw)) * (PT_BVH_STACK_SIZE - PT_WF_TLAS_LDS_STACK) + (tsp - PT_WF_TLAS_LDS_STACK)];
+        return 0u;
+    };
+
+    while (true) {
+        uint32_t nIdle = (uint32_t)__popcll(__ballot(!have));
+        while (cursor < nItems && (nIdle >= PT_WF_REFILL || nIdle == 64u)) {
+            const unsigned long long idle = __ballot(!have);
+            const uint32_t rankI = (uint32_t)__popcll(idle & ltMask);
+            const uint32_t item = cursor + lane;
+            const uint32_t kind = item / PT_WF_RANGE;
+            const uint32_t slot = slotBase + (item & (PT_WF_RANGE - 1u));
+            bool valid = item < nItems && slot < B.numSlots;
+            if (valid) valid = ray_exists(B.flags[slot], kind);
+            const unsigned long long V = __ballot(valid);
+            const uint32_t nV = (uint32_t)__popcll(V);
+            const uint32_t take = nIdle < nV ? nIdle : nV;
+            const uint32_t rankV = (uint32_t)__popcll(V & ltMask);
+            uint32_t consumed = 64u;
+            if (take < nV) consumed = (uint32_t)__ffsll((long long)__ballot(valid && rankV == take)) - 1u;
+            if (valid && rankV < take) xchg[rankV] = item;
+            __builtin_amdgcn_wave_barrier();
+            if (!have && rankI < take) {
+                const uint32_t it = xchg[rankI];
+                myKind = it / PT_WF_RANGE;
+                mySlot = slotBase + (it & (PT_WF_RANGE - 1u));
+                v3 d;
+                if (myKind == 0u) { O = xyz(B.ro[mySlot]); d = xyz(B.rd[mySlot]); }
+                else { O = xyz(B.neeO[mySlot]); d = xyz(myKind == 1u ? B.envD[mySlot] : B.lightD[mySlot]); }
+                if (myKind == 0u) cn.closestRays++; else cn.shadowRays++;
+                if (pt_isnan(O.x) || pt_isnan(O.y) || pt_isnan(O.z) || pt_isnan(d.x) || pt_isnan(d.y) || pt_isnan(d.z)) {
+                    if (myKind == 0u) store_miss(B, mySlot);              // NaN ray: certain miss (traverse_tlas)
+                    else store_occlusion(B, myKind, mySlot, false);
+                } else {
+                    const v3 D = normalize3(d);                           // tlas.hlsl:238-240
+                    rD = mk3(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
+                    rs.hit.t = PT_FAR_PLANE;
+                    rs.anyHit = myKind != 0u;
+                    nodeIndex = 0u; tsp = 0u; instLeft = 0u; needPop = false; inBlas = false;
+                    have = true;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            cursor += consumed;
+            nIdle = (uint32_t)__popcll(__ballot(!have));
+        }
+        if (nIdle == 64u) break;
+        const uint32_t stopAt = cursor < nItems ? PT_WF_REFILL : 64u;
+        do {
+            // ---- (rare) a lane that is between instances: instance epilogue is done; walk the TLAS to the next instance
+            if (have && !inBlas) {
+                bool finished = false;
+                while (true) {
+                    if (instLeft > 0u) {
+                        // enter the next instance of the current TLAS leaf (tlas.hlsl:129-147)
+                        instIndex = pt_asuint(T[S.tlasIndexOffset + nextInst]);
+                        nextInst++; instLeft--;
+                        const float4* ip = S.instances + (size_t)instIndex * 9;
+                        const float4 w0 = ip[4], w1 = ip[5], w2 = ip[6], w3 = ip[7], ints = ip[8];
+                        if (STATS) cn.instanceVisits++;
+                        nodeOffset = pt_asuint(ints.x); triOffset = pt_asuint(ints.y); attrOffset = pt_asuint(ints.z);
+                        const v3 wd = xyz(myKind == 0u ? B.rd[mySlot] : (myKind == 1u ? B.envD[mySlot] : B.lightD[mySlot]));
+                        const v4 lo4 = mul44c(w0, w1, w2, w3, v4{O.x, O.y, O.z, 1.0f});
+                        const v4 ld4 = mul44c(w0, w1, w2, w3, v4{wd.x, wd.y, wd.z, 0.0f});
+                        const float tKeep = rs.hit.t;
+                        ray_begin(rs, mk3(lo4.x, lo4.y, lo4.z), mk3(ld4.x, ld4.y, ld4.z), myKind != 0u);
+                        rs.hit.t = tKeep;
+                        hitFound = false;
+                        inBlas = true;
+                        break;
+                    }
+                    if (needPop) {
+                        if (tsp == 0u) { finished = true; break; }
+                        nodeIndex = tpop();
+                        needPop = false;
+                    }
+                    // visit TLAS node nodeIndex (tlas.hlsl:246-331)
+                    const float4* np = (const float4*)(T + (size_t)nodeIndex * 16u);
+                    const float4 a = np[0], b = np[1], c = np[2], e = np[3];
+                    if (STATS) cn.tlasNodeVisits++;
+                    const uint32_t instanceCount = pt_asuint(c.w);
+                    if (instanceCount == 0u) {
+                        uint32_t left = pt_asuint(a.w), right = pt_asuint(b.w);
+                        const v3 t1a = (mk3(a.x, a.y, a.z) - O) * rD, t2a = (mk3(b.x, b.y, b.z) - O) * rD;
+                        const float tmina = pt_max(pt_max(pt_max(pt_min(t1a.x, t2a.x), pt_min(t1a.y, t2a.y)), pt_min(t1a.z, t2a.z)), 0.0f);
+                        const float tmaxa = pt_min(pt_min(pt_min(pt_max(t1a.x, t2a.x), pt_max(t1a.y, t2a.y)), pt_max(t1a.z, t2a.z)), rs.hit.t);
+                        float dist1 = tmina > tmaxa ? PT_FAR_PLANE : tmina;
+                        const v3 t1b = (mk3(c.x, c.y, c.z) - O) * rD, t2b = (mk3(e.x, e.y, e.z) - O) * rD;
+                        const float tminb = pt_max(pt_max(pt_max(pt_min(t1b.x, t2b.x), pt_min(t1b.y, t2b.y)), pt_min(t1b.z, t2b.z)), 0.0f);
+                        const float tmaxb = pt_min(pt_min(pt_min(pt_max(t1b.x, t2b.x), pt_max(t1b.y, t2b.y)), pt_max(t1b.z, t2b.z)), rs.hit.t);
+                        float dist2 = tminb > tmaxb ? PT_FAR_PLANE : tminb;
+                        if (dist1 > dist2) {
+                            const float h = dist1; dist1 = dist2; dist2 = h;
+                            const uint32_t t = left; left = right; right = t;
+                        }
+                        if (dist1 == PT_FAR_PLANE) needPop = true;
+                        else {
+                            nodeIndex = left;
+                            if (dist2 != PT_FAR_PLANE) tpush(right);
+                        }
+                    } else {
+                        nextInst = pt_asuint(e.w);
+                        instLeft = instanceCount;
+                        needPop = true;                                    // after the leaf's instances
+                    }
+                }
+                if (finished) {
+                    if (myKind == 0u) { if (!(rs.hit.t < PT_FAR_PLANE)) store_miss(B, mySlot); }
+                    else store_occlusion(B, myKind, mySlot, false);
+                    have = false;
+                }
+            }
+            // ---- the hot step: one CWBVH iteration inside the current instance
+            if (have && inBlas) {
+                const float tBefore = rs.hit.t;
+                bool blasDone = false;
+                {
+                    // ray_step with instance offsets and the HAS_TLAS triangle test (tlas.hlsl:149-206)
+                    if (rs.ng.y > 0x00FFFFFFu) {
+                        cwbvh_visit_node<STATS>(S.nodes, nodeOffset, rs.o, rs.invDir, rs.octinv4, rs.hit.t, rs.ng, rs.tg, rs.sp, rs.overflow, st, cn);
+                    } else {
+                        rs.tg = rs.ng;
+                        rs.ng = make_uint2(0u, 0u);
+                    }
+                    while (rs.tg.y != 0u) {
+                        const uint32_t triangleIndex = 31u - (uint32_t)__clz((int)rs.tg.y);
+                        const uint32_t triAddr = rs.tg.x + triangleIndex * 3u;
+                        hitFound = intersect_triangle_inst(S.tris, triOffset + triAddr, attrOffset, rs.o, rs.d, rs.hit) | hitFound;
+                        if (STATS) cn.triTests++;
+                        rs.tg.y -= 1u << triangleIndex;
+                        if (rs.anyHit && hitFound) { rs.tg.y = 0u; rs.ng.y = 0u; rs.sp = 0u; }
+                    }
+                    if (rs.ng.y <= 0x00FFFFFFu) {
+                        if (rs.sp > 0u) { --rs.sp; rs.ng = stack_pop(st, rs.sp); }
+                        else blasDone = true;
+                    }
+                }
+                if (myKind == 0u && rs.hit.t < tBefore) B.hit[mySlot] = make_float4(rs.hit.t, rs.hit.u, rs.hit.v, pt_asfloat(rs.hit.triIndex));
+                if (blasDone) {
+                    if (STATS && rs.overflow) cn.overflows++;
+                    inBlas = false;
+                    if (rs.anyHit) {
+                        if (hitFound) { store_occlusion(B, myKind, mySlot, true); have = false; }       // stopNow (tlas.hlsl:196-200)
+                    } else if (hitFound) {
+                        // tlas.hlsl:208-229: world-space hit position and distance of the instance that improved the hit
+                        if (STATS) cn.attrFetches++;
+                        const float4* ip = S.instances + (size_t)instIndex * 9;
+                        const float4 l0 = ip[0], l1 = ip[1], l2 = ip[2], l3 = ip[3];
+                        const v3 lp = rs.o + rs.hit.t * rs.d;
+                        const v4 wp = mul44c(l0, l1, l2, l3, v4{lp.x, lp.y, lp.z, 1.0f});
+                        const v3 pos = mk3(wp.x, wp.y, wp.z);
+                        rs.hit.t = length3(pos - O);
+                        ((float*)&B.hit[mySlot])[0] = rs.hit.t;
+                        B.hit2[mySlot] = make_float4(pos.x, pos.y, pos.z, pt_asfloat(instIndex));
+                    }
+                }
+            }
+            nIdle = (uint32_t)__popcll(__ballot(!have));
+        } while (nIdle < stopAt);
+    }
+    __builtin_amdgcn_wave_barrier();
+    flush_counters<STATS>(cn, B.statRows, (B.numSlots >> 6) + *PT_LDS_WORD(s_gw), lane);
+}
+
+// ------------------------------------------------------------------------------------------
 // persistent trace (schedule 1): the refill kernel above, made persistent.  The grid is exactly the number of
 // waves the chip holds; a wave that has scanned its 64-slot chunk pulls the NEXT chunk index from a device counter
 // while its remaining rays are still in flight, so lanes are refilled continuously and nothing drains until the
@@ -718,7 +935,8 @@ hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const fl
     uint32_t launches = 0;
     hipError_t e;
     const bool tlas = S.hasTlas != 0u;
-    if (tlas) traceVariant = 1;          // two-level traversal runs in the one-ray-per-lane trace kernel (not resumable yet)
+    const bool tlasRefill = tlas && traceVariant == 2;    // schedule 1: two-level traversal through the refill scheduler
+    if (tlas) traceVariant = 1;          // schedules 2, 3: the one-ray-per-lane trace kernel
     if ((e = hipMemsetAsync(B.aliveFlags, 0, sizeof(uint32_t) * B.maxIterations, stream)) != hipSuccess) return e;
     hipLaunchKernelGGL(pt_wf_init, dim3(nb), dim3(256), 0, stream, P, tm, B);
     launches++;
@@ -744,6 +962,9 @@ hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const fl
                 else hipLaunchKernelGGL((pt_wf_trace_refill<false, true>), dim3(tailBlocks), dim3(64), 0, stream, S, B);
                 launches++;
             }
+        } else if (tlas && tlasRefill) {
+            if (fullStats) hipLaunchKernelGGL(pt_wf_trace_refill_tlas<true>, dim3(refillBlocks), dim3(64), 0, stream, S, B);
+            else hipLaunchKernelGGL(pt_wf_trace_refill_tlas<false>, dim3(refillBlocks), dim3(64), 0, stream, S, B);
         } else if (tlas) {
             if (fullStats) hipLaunchKernelGGL((pt_wf_trace<true, true>), dim3(nb * 3u), dim3(256), 0, stream, S, B);
             else hipLaunchKernelGGL((pt_wf_trace<false, true>), dim3(nb * 3u), dim3(256), 0, stream, S, B);
