@@ -123,7 +123,7 @@ int ensure_wavefront(PTContext* c, PTContext::WfSet& set, uint32_t numSlots, uin
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t spillBytes = n * (size_t)(PT_BVH_STACK_SIZE - PT_WF_LDS_STACK) * sizeof(uint2);
     const size_t suspBytes = (n >> 6) * (size_t)PT_WF_SUSPEND_MAX * 6 * sizeof(uint4);
-    const size_t tlasSpillBytes = needTlas ? n * (size_t)(PT_BVH_STACK_SIZE - 8) * sizeof(uint32_t) : 0;
+    const size_t tlasSpillBytes = needTlas ? n * (size_t)PT_BVH_STACK_SIZE * sizeof(uint32_t) : 0;
     size_t total = align(n * 4) * 2 + align(n * 16) * 13 + align(n * 2) + align((size_t)maxIterations * 4) +
                    align((size_t)numRows * 16 * 8) + align(8 * 32 * 4) + align(spillBytes) + align(suspBytes) + align((n >> 6) * 4) + align(tlasSpillBytes);
     if (set.arena && set.arenaBytes < total) { hipFree(set.arena); set.arena = nullptr; set.arenaBytes = 0; }

@@ -72,7 +72,7 @@ struct PTWfBuffers {
     float4* hit2;               // [numSlots] HAS_TLAS only: (world hit position, instance index bits)
     uint8_t* occl;              // [2][numSlots] written by trace kinds 1, 2
     uint2* stackSpill;          // [numSlots][32 - PT_WF_LDS_STACK]: traversal-stack entries beyond the LDS part (refill / persistent trace kernels)
-    uint32_t* tlasSpill;        // [numSlots][32 - 8]: HAS_TLAS refill kernel, TLAS-stack entries beyond its LDS part (allocated for HAS_TLAS scenes only)
+    uint32_t* tlasSpill;        // [numSlots][32]: HAS_TLAS refill kernel, TLAS-stack entries beyond its LDS part (allocated for HAS_TLAS scenes only)
     uint4* susp;                // [numSlots / 64][PT_WF_SUSPEND_MAX][6]: suspended rays of the refill trace kernel (pt_wavefront.hip)
     uint32_t* suspCount;        // [numSlots / 64]
     uint32_t* aliveFlags;       // [maxIterations]

@@ -209,6 +209,7 @@ PT_DEV bool ray_exists(uint32_t f, uint32_t kind)
 #endif
 #define PT_WF_SUSP_ROWS 6u      // uint4 rows per record
 
+#if PT_WF_SUSPEND > 0
 template <class ST>
 PT_DEV void suspend_ray(const PTWfBuffers& B, uint32_t rec, uint32_t slot, uint32_t kind, const RayState& r, ST& st)
 {
@@ -221,7 +222,12 @@ PT_DEV void suspend_ray(const PTWfBuffers& B, uint32_t rec, uint32_t slot, uint3
         p[2u + e] = make_uint4(x.x, x.y, y.x, y.y);
     }
 }
+#else
+template <class ST> PT_DEV void suspend_ray(const PTWfBuffers&, uint32_t, uint32_t, uint32_t, const RayState&, ST&) {}
+#endif
+#if PT_WF_SUSPEND > 0
 static_assert(PT_WF_LDS_STACK == 8, "a suspension record holds the eight LDS stack entries");
+#endif
 
 template <bool STATS, bool TAIL>
 __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(DScene S, PTWfBuffers B)
@@ -406,7 +412,9 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(
 // a second, narrow LDS stack for TLAS node indices; the world-space ray is re-read from the slot arrays when an instance is
 // entered.  Same per-ray operation order as traverse_tlas, so frames and all counters stay bit-identical.
 // ------------------------------------------------------------------------------------------
+#ifndef PT_WF_TLAS_LDS_STACK
 #define PT_WF_TLAS_LDS_STACK 8u
+#endif
 
 #ifndef PT_WF_TLAS_MIN_WAVES
 #define PT_WF_TLAS_MIN_WAVES 5
@@ -444,13 +452,13 @@ __global__ __launch_bounds__(64, PT_WF_TLAS_MIN_WAVES) void pt_wf_trace_refill_t
 
     auto tpush = [&](uint32_t v) {
         if (tsp < PT_WF_TLAS_LDS_STACK) tlds[tsp * 64u] = v;
-        else if (tsp < PT_BVH_STACK_SIZE) B.tlasSpill[spill_row(PT_LDS_WORD(s_gw)) * (PT_BVH_STACK_SIZE - PT_WF_TLAS_LDS_STACK) + (tsp - PT_WF_TLAS_LDS_STACK)] = v;
+        else if (tsp < PT_BVH_STACK_SIZE) B.tlasSpill[spill_row(PT_LDS_WORD(s_gw)) * PT_BVH_STACK_SIZE + tsp] = v;
         tsp++;
     };
     auto tpop = [&]() -> uint32_t {
         --tsp;
         if (tsp < PT_WF_TLAS_LDS_STACK) return tlds[tsp * 64u];
-        if (tsp < PT_BVH_STACK_SIZE) return B.tlasSpill[spill_row(PT_LDS_WORD(s_gw)) * (PT_BVH_STACK_SIZE - PT_WF_TLAS_LDS_STACK) + (tsp - PT_WF_TLAS_LDS_STACK)];
+        if (tsp < PT_BVH_STACK_SIZE) return B.tlasSpill[spill_row(PT_LDS_WORD(s_gw)) * PT_BVH_STACK_SIZE + tsp];
         return 0u;
     };
 
