@@ -1,5 +1,5 @@
-"""A stress build of the library (make -C unity_webgpu_pathtracer_amd/csrc stress) keeps only 2 CWBVH-stack and 1 TLAS-stack
-entries per lane in LDS, so every ray goes through the overflow path into the HBM slab that the default build (8 entries) takes
+"""A stress build of the library (make -C unity_webgpu_pathtracer_amd/csrc stress) keeps only ONE CWBVH-stack and ONE TLAS-stack
+entry per lane in LDS, so every ray goes through the overflow path into the HBM slab that the default build (8 entries) takes
 only for unusually deep trees.  Frames and all counters must still equal the oracle's bit for bit."""
 import os
 import subprocess
@@ -47,4 +47,4 @@ def test_small_stack_build_is_bit_exact(tmp_path, oracle):
         assert np.array_equal(got[name].view(np.uint32), ref.view(np.uint32)), name
         d = st.as_dict()
         assert np.array_equal(got[name + "_stats"], np.array([d[k] for k in sorted(d)], dtype=np.uint64)), name
-        assert d["maxStackDepth"] > 2                               # deeper than the stress build's LDS part: the slab was used
+        assert d["maxStackDepth"] >= 2                              # deeper than the stress build's LDS part: the slab was used
