@@ -54,9 +54,10 @@ _oracle = None
 def load_oracle():
     global _oracle
     if _oracle is None:
-        if not os.path.exists(ORACLE_SO):
+        path = os.environ.get("PT_ORACLE_LIB") or ORACLE_SO       # PT_ORACLE_LIB: the sanitizer build (make -C oracle asan-test)
+        if not os.path.exists(path):
             build(ref=False)
-        lib = C.CDLL(ORACLE_SO)
+        lib = C.CDLL(path)
         lib.oracle_render.restype = C.c_int
         lib.oracle_render.argtypes = [C.POINTER(abi.PTSceneDesc), C.POINTER(abi.PTFrameParams), C.c_void_p,
                                       C.c_void_p, C.POINTER(abi.PTStats), C.POINTER(OracleOptions)]

@@ -1,7 +1,26 @@
 // bvh_builder.cpp — acceleration-structure builders behind BuildBVH / BuildTLAS.
 //
-// Own implementation (no third-party code) of the construction pipeline the reference plugin runs
-// through tinybvh v1.6.7 with TINYBVH_NO_SIMD / NO_THREADED_BUILDS (Assets/Plugins/Web/plugin.h:9-11):
+// DERIVED FROM tinybvh v1.6.7 (https://github.com/jbikker/tinybvh, tiny_bvh.h as vendored by the reference at
+// Assets/Plugins/Web/tiny_bvh.h), Copyright (c) 2024-2025 Jacco Bikker, MIT License:
+//
+//   Permission is hereby granted, free of charge, to any person obtaining a copy of this software and associated
+//   documentation files (the "Software"), to deal in the Software without restriction, including without limitation the
+//   rights to use, copy, modify, merge, publish, distribute, sublicense, and/or sell copies of the Software, and to permit
+//   persons to whom the Software is furnished to do so, subject to the following conditions: The above copyright notice and
+//   this permission notice shall be included in all copies or substantial portions of the Software.
+//   THE SOFTWARE IS PROVIDED "AS IS", WITHOUT WARRANTY OF ANY KIND, EXPRESS OR IMPLIED, INCLUDING BUT NOT LIMITED TO THE
+//   WARRANTIES OF MERCHANTABILITY, FITNESS FOR A PARTICULAR PURPOSE AND NONINFRINGEMENT.  IN NO EVENT SHALL THE AUTHORS OR
+//   COPYRIGHT HOLDERS BE LIABLE FOR ANY CLAIM, DAMAGES OR OTHER LIABILITY, WHETHER IN AN ACTION OF CONTRACT, TORT OR
+//   OTHERWISE, ARISING FROM, OUT OF OR IN CONNECTION WITH THE SOFTWARE OR THE USE OR OTHER DEALINGS IN THE SOFTWARE.
+//
+// Why it is a restatement and not an independent design: BuildBVH's output must be BYTE-IDENTICAL to the reference plugin's
+// (the C# host and every downstream fixture consume those bytes), and byte identity of a greedy, float-driven construction
+// forces the algorithm, its traversal order and the order of every float operation.  The functions below therefore follow
+// the cited tinybvh routines step by step -- with names of our own only where the code is not a direct counterpart -- and
+// are licensed under the terms above.  (The builder that is an independent design is bvh_builder_gpu.hip.)
+//
+// The construction pipeline the reference plugin runs through tinybvh with TINYBVH_NO_SIMD / NO_THREADED_BUILDS
+// (Assets/Plugins/Web/plugin.h:9-11):
 //
 //   BuildBVH  (plugin.cpp:35-40  -> tiny_bvh.h:5787-5795)
 //     1. binned-SAH binary BVH, 8 bins, c_trav = c_int = 1          (tiny_bvh.h:2221-2290, 2292-2421)

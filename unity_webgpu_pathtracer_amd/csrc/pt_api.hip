@@ -6,6 +6,8 @@
 // There is NO CPU fallback: without a HIP device PTCreate fails with PT_ERR_NO_DEVICE.
 #include "pt_launch.h"
 
+#include <rocprofiler-sdk-roctx/roctx.h>      // ranges around every pass / scene upload / build: rocprofv3 --marker-trace shows them
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -44,6 +46,11 @@ struct DeviceBuffer {
 };
 
 struct EventPair { hipEvent_t start, stop; uint32_t launches; };
+
+struct RoctxRange {                      // the reference wraps its dispatch in _cmd.BeginSample / EndSample("Path Tracer") (PathTracer.cs:226,252)
+    explicit RoctxRange(const char* name) { roctxRangePushA(name); }
+    ~RoctxRange() { roctxRangePop(); }
+};
 
 } // namespace
 
@@ -321,6 +328,7 @@ int effective_schedule(const PTContext* c)
 int render_to(PTContext* c, const PTFrameParams* hostParams, float4* dOut, const float4* dAcc)
 {
     if (!c) return fail(PT_ERR_INVALID_ARG, "ctx == NULL");
+    RoctxRange range("PT pass (enqueue)");
     PTFrameParams params;
     int rc = import_params(hostParams, params);
     if (rc) return rc;
@@ -438,6 +446,7 @@ PT_API int PTSetScene(PTContext* c, const PTSceneDesc* hostScene)
     memset(&sceneCopy, 0, sizeof(sceneCopy));
     memcpy(&sceneCopy, hostScene, hostScene->structSize < sizeof(sceneCopy) ? hostScene->structSize : sizeof(sceneCopy));
     const PTSceneDesc* s = &sceneCopy;
+    RoctxRange range("PTSetScene (validate + upload)");
     const bool tlasOn = (s->features & PT_FEATURE_HAS_TLAS) != 0;
     if (tlasOn && (!s->tlasData || s->tlasDataFloats < 16 || !s->gpuInstances || s->instanceCount == 0 ||
                    s->tlasIndexOffset >= s->tlasDataFloats || s->tlasIndexOffset % 16 != 0))
