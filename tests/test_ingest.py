@@ -238,3 +238,114 @@ def test_gpu_obj_to_frame(tmp_path, oracle, ctx):
     assert np.array_equal(gpu.view(np.uint32), ref.view(np.uint32))
     assert gpu[..., :3].std() > 0.05                                  # an actual picture, not a constant
     pt.close()
+
+
+# ---------------------------------------------------------------------------------------
+# binary glTF (.glb): the format the reference's own models come in (UnityGLTF; Assets/Examples/Models/DamagedHelmet.glb)
+# ---------------------------------------------------------------------------------------
+def _glb_meshes(rng):
+    cube, _ = None, None
+    a = _random_mesh(rng, 40, 30, True, np.uint16, normals=True, tangents=False, uvs=True, mat=1)
+    b = _random_mesh(rng, 300, 90, True, np.uint32, normals=True, tangents=False, uvs=False, mat=0)
+    c = _random_mesh(rng, 27, 9, False, np.uint16, normals=False, tangents=False, uvs=True, mat=2)
+    d = _random_mesh(rng, 12, 7, True, np.uint8, normals=True, tangents=False, uvs=True, mat=0)
+    return [a, b, c, d]
+
+
+@pytest.mark.parametrize("interleave", [False, True])
+def test_glb_roundtrip(tmp_path, interleave):
+    """write_glb -> load_glb: separate and interleaved (strided) buffer views, 8/16/32-bit and absent indices, node matrices;
+    without the handedness conversion the data comes back bit for bit, with it z is negated and the winding reversed."""
+    rng = np.random.RandomState(9)
+    meshes = _glb_meshes(rng)
+    mats = [np.eye(4), _trs(), np.diag([2.0, 2.0, 2.0, 1.0]), _trs() @ _trs()]
+    gl_mats = [{"name": "m0", "pbrMetallicRoughness": {"baseColorFactor": [0.5, 0.25, 1.0, 1.0], "metallicFactor": 0.0, "roughnessFactor": 0.4}},
+               {"name": "m1", "alphaMode": "MASK", "alphaCutoff": 0.3, "emissiveFactor": [1, 2, 3]}, {"name": "m2", "alphaMode": "BLEND"}]
+    path = str(tmp_path / "scene.glb")
+    ingest.write_glb(path, meshes, materials=gl_mats, node_matrices=mats, interleave=interleave)
+    back, materials, images = ingest.load_glb(path, unity_handedness=False)
+    assert len(back) == 4 and images == [] and [m["name"] for m in materials] == ["m0", "m1", "m2"]
+    assert materials[0]["base_color"] == (0.5, 0.25, 1.0, 1.0) and materials[0]["roughness"] == 0.4 and materials[1]["alpha_mode"] == 1
+    assert materials[1]["alpha_cutoff"] == 0.3 and materials[1]["emissive"] == (1, 2, 3) and materials[2]["alpha_mode"] == 2 and materials[0]["tex_base"] == -1
+    for src, got, mat in zip(meshes, back, mats):
+        assert np.array_equal(got.positions, src.positions) and got.material_index == src.material_index
+        assert (src.normals is None) == (got.normals is None) and (src.normals is None or np.array_equal(got.normals, src.normals))
+        assert (src.uvs is None) == (got.uvs is None) and (src.uvs is None or np.array_equal(got.uvs, src.uvs))
+        assert (src.indices is None) == (got.indices is None) and (src.indices is None or np.array_equal(got.indices.astype(np.int64), src.indices.astype(np.int64)))
+        assert np.allclose(got.local_to_world, mat) and got.triangle_count == src.triangle_count
+    flipped, _, _ = ingest.load_glb(path)                                   # UnityGLTF's right- to left-handed conversion
+    for src, got, mat in zip(meshes, flipped, mats):
+        assert np.array_equal(got.positions[:, :2], src.positions[:, :2] if src.indices is not None else src.positions.reshape(-1, 3, 3)[:, ::-1].reshape(-1, 3)[:, :2])
+        if src.indices is not None:
+            assert np.array_equal(got.positions[:, 2], -src.positions[:, 2])
+            assert np.array_equal(got.indices.reshape(-1, 3)[:, ::-1].reshape(-1).astype(np.int64), src.indices.astype(np.int64))
+        f = np.diag([1.0, 1.0, -1.0, 1.0])
+        assert np.allclose(got.local_to_world, f @ mat @ f)
+    packed = ingest.pack_gltf_materials(materials)
+    assert packed.shape == (3, 32) and np.allclose(packed[0, :3], [0.5, 0.25, 1.0], rtol=1e-5) and packed[1, 12] == 1.0 and packed[1, 7] == np.float32(0.3)
+
+
+def test_glb_rejects_malformed_files(tmp_path):
+    rng = np.random.RandomState(2)
+    path = str(tmp_path / "a.glb")
+    ingest.write_glb(path, _glb_meshes(rng)[:1])
+    raw = bytearray(open(path, "rb").read())
+    for mutate in (lambda b: b.__setitem__(slice(0, 4), b"glTX"), lambda b: b.__setitem__(slice(4, 8), (3).to_bytes(4, "little")),
+                   lambda b: b.__delitem__(slice(len(b) - 200, len(b)))):
+        bad = bytearray(raw)
+        mutate(bad)
+        p2 = str(tmp_path / "bad.glb")
+        open(p2, "wb").write(bytes(bad))
+        with pytest.raises(ValueError):
+            ingest.load_glb(p2)
+    m = _glb_meshes(rng)[0]
+    m.indices[5] = 60000                                                   # index past the vertex array
+    ingest.write_glb(path, [m])
+    with pytest.raises(ValueError):
+        ingest.load_glb(path)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/Assets/Examples/Models/DamagedHelmet.glb"), reason="reference snapshot not present (GPU box)")
+def test_glb_reader_on_the_reference_helmet():
+    """The one real model in the reference snapshot, read as DATA (no reference code runs): geometry, transform, material."""
+    meshes, materials, images = ingest.load_glb("/root/reference/Assets/Examples/Models/DamagedHelmet.glb", load_images=False)
+    assert len(meshes) == 1 and meshes[0].triangle_count == 15452 and meshes[0].positions.shape == (14556, 3)
+    assert meshes[0].normals is not None and meshes[0].uvs is not None and meshes[0].indices.dtype == np.uint16
+    assert np.isfinite(meshes[0].positions).all() and np.allclose(np.linalg.norm(meshes[0].normals, axis=1), 1.0, atol=1e-3)
+    assert materials[0]["tex_base"] == 0 and materials[0]["tex_mr"] == 1 and materials[0]["tex_emission"] == 2 and materials[0]["metallic"] == 1.0
+    assert abs(np.linalg.det(meshes[0].local_to_world[:3, :3]) - 1.0) < 1e-5
+
+
+@pytest.mark.gpu
+def test_gpu_glb_to_frame(tmp_path, oracle, ctx):
+    """GLB file (written by this test) -> load_glb -> ingestion kernels (PTProcessMeshes) -> BuildBVH -> render: the frame equals
+    the oracle's frame of the same buffers, and the device-built BVH (PTBuildBVHDevice) renders the same picture."""
+    from unity_webgpu_pathtracer_amd.pathtracer import PathTracer
+    obj = tmp_path / "cube.obj"
+    obj.write_text(CUBE_OBJ)
+    cube, _ = ingest.load_obj(str(obj))
+    floor = ingest.Mesh(np.array([[-6, -1.5, -6], [6, -1.5, -6], [6, -1.5, 6], [-6, -1.5, 6]], np.float32),
+                        np.tile(np.array([[0, 1, 0]], np.float32), (4, 1)), None, np.array([[0, 0], [4, 0], [4, 4], [0, 4]], np.float32),
+                        np.array([0, 2, 1, 0, 3, 2], np.uint16), np.eye(4), 2)
+    src = cube + [floor]
+    node_m = [_trs() @ np.diag([0.4, 0.4, 0.4, 1.0])] * len(cube) + [np.eye(4)]
+    gl_mats = [{"pbrMetallicRoughness": {"baseColorFactor": [0.8, 0.1, 0.1, 1], "metallicFactor": 0.0, "roughnessFactor": 0.4}},
+               {"pbrMetallicRoughness": {"baseColorFactor": [0.1, 0.7, 0.2, 1], "metallicFactor": 1.0, "roughnessFactor": 0.2}},
+               {"pbrMetallicRoughness": {"baseColorFactor": [1, 1, 1, 1], "metallicFactor": 0.0, "roughnessFactor": 0.9}}]
+    path = str(tmp_path / "scene.glb")
+    ingest.write_glb(path, src, materials=gl_mats, node_matrices=node_m, interleave=True)
+    meshes, materials, _ = ingest.load_glb(path, unity_handedness=False)
+    cam = scenes.Camera(eye=(0.5, 2.5, -7.0), target=(3.0, -0.8, 0.25), vfov_deg=40.0)
+    s = ingest.scene_from_meshes(ctx, meshes, ingest.pack_gltf_materials(materials), cam, environment_mode=1, environment_intensity=1.0)
+    assert s.tri_count == 14
+    frames = []
+    for dev in (None, 0):
+        pt = PathTracer(s, width=96, height=64, samplesPerPass=3, build_device=dev)
+        p = pt.params(seed=0xB0B)
+        pt.render_pass(p)
+        gpu = pt.readback()
+        ref, _ = oracle.render(oracle.buffers_from_bvhscene(pt._bvhScene), p)
+        assert np.array_equal(gpu.view(np.uint32), ref.view(np.uint32))
+        frames.append(gpu)
+        pt.close()
+    assert frames[0][..., :3].std() > 0.05 and np.array_equal(frames[0], frames[1])
