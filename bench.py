@@ -251,13 +251,15 @@ def main():
         main_res.setdefault("counters_per_launch", {})
         main_res.setdefault("max_stack_depth", 0)
         achieved = main_res["alg_bytes_per_launch"] / kernel_s / 1e9 if kernel_s > 0 else 0.0
-        traffic = None
+        traffic, traffic_source = None, None
         tj = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tj):
             try:
                 rec = json.load(open(tj))
                 if rec.get("workload") == args.workload and rec.get("n_gpus", 1) == world:
                     traffic = rec.get("bytes_per_launch")
+                    # NOT measured in this run: counters need rocprofv3; the committed summary of the same command is quoted
+                    traffic_source = "committed profile, not this run: " + rec.get("source", "profiles/hbm_traffic.json")
             except Exception:
                 traffic = None
         valu = None
@@ -266,10 +268,12 @@ def main():
             try:
                 rec = json.load(open(vj))
                 if rec.get("workload") == args.workload and rec.get("n_gpus", 1) == world and kernel_s > 0:
-                    # second roofline: wave-level VALU instructions per pass (SQ_INSTS_VALU, profiled) against the issue peak
-                    # (256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction) over the kernel time measured NOW
+                    # second roofline: wave-level VALU instructions per pass (SQ_INSTS_VALU, committed profile) against the
+                    # MEASURED wave64 issue peak (tools/microbench/valu_issue.hip) over the kernel time measured NOW
                     valu = {"wave_insts_per_launch": rec["valu_wave_insts_per_launch"], "issue_peak_per_s": rec["issue_peak_wave_insts_per_s"],
-                            "frac": round(rec["valu_wave_insts_per_launch"] / kernel_s / rec["issue_peak_wave_insts_per_s"], 4)}
+                            "frac": round(rec["valu_wave_insts_per_launch"] / kernel_s / rec["issue_peak_wave_insts_per_s"], 4),
+                            "valu_source": "committed profile, not this run: " + rec.get("source", "profiles/valu_insts.json"),
+                            "peak_source": rec.get("issue_peak_source", "")}
             except Exception:
                 valu = None
         out = {
@@ -283,15 +287,17 @@ def main():
                        "frame_crc32": main_res["frame_crc32"],
                        "sharding": "interleaved 16x16 blocks, one RCCL gather of owned tiles per frame" if distributed else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                         "kernel": {0: "pt_megakernel", 1: "pt_wf_trace_refill + pt_wf_shade (whole pass)", 2: "pt_wf_trace + pt_wf_shade (whole pass)",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": {0: "pt_megakernel", 1: "pt_wf_trace_refill (main + tail) + pt_wf_shade (whole pass)", 2: "pt_wf_trace + pt_wf_shade (whole pass)",
                                     3: "pt_wf_trace_persist + pt_wf_shade (whole pass)"}[main_res["schedule"]],
                          "kernel_ms": round(main_res["kernel_ms"], 4), "pass_span_ms": round(main_res["pass_span_ms"], 4),
                          "algorithmic_bytes_per_launch": round(main_res["alg_bytes_per_launch"]),
                          "counters_per_launch": {k: round(v) for k, v in main_res["counters_per_launch"].items()},
                          "max_stack_depth": main_res["max_stack_depth"],
                          "valu_issue": valu,
-                         "note": "rank-0 kernel; working set is Infinity-Cache resident; the pass is VALU-issue-bound under divergence (valu_issue.frac, DESIGN.md 5.4)"},
+                         "note": "rank-0 kernels; achieved = algorithmic bytes of a pass / its device time (HIP events on the context stream, passes overlap); "
+                                 "the scene is Infinity-Cache resident, so HBM is the nominal roof only: the pass is bound by divergent-gather throughput of the "
+                                 "vector memory path and by VALU issue under ~50 % lane utilisation (DESIGN.md 5.4)"},
         }
     if not args.no_extra and not distributed:
         extra = {}

@@ -21,8 +21,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def short(name):
     import re
-    m = re.search(r"(pt_\w+)(<\w+>)?", name)
-    return (m.group(1) + (m.group(2) or "")) if m else name[:40]
+    m = re.search(r"(pt_\w+)(<[\w, ]+>)?", name)
+    return (m.group(1) + (m.group(2) or "").replace(" ", "")) if m else name[:40]
+
+
+def measured_valu_peak():
+    """Wave64 VALU issue peak of this chip, MEASURED by tools/microbench/valu_issue.hip (independent v_fma_f32 streams, 8 waves
+    per SIMD, every CU): profiles/r02_valu_issue.json.  Round 1 assumed 4 cycles per wave instruction (6.1e11/s); the measurement
+    says 2.3 cycles at the nominal clock = 1.08e12/s (the microarchitecture guide: SIMD-32, 2 cycles)."""
+    f = os.path.join(ROOT, "profiles", "r02_valu_issue.json")
+    rec = json.load(open(f))
+    best = max(r["wave_insts_per_s"] for r in rec["results"] if r["kind"] == "indep")
+    return best, "profiles/r02_valu_issue.json (tools/microbench/valu_issue.hip: independent v_fma_f32, 8 waves/SIMD, all CUs)"
 
 
 def per_pass(rows, value_of):
@@ -79,19 +89,38 @@ def main():
     f = glob.glob(os.path.join(base, f"{tag}_valu", "*", "*_counter_collection.csv"))
     if f:
         allrows = [r for r in csv.DictReader(open(f[0])) if "pt_" in r["Kernel_Name"]]
-        for counter in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS"):
+        for counter in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"):
             rows = [r for r in allrows if r["Counter_Name"] == counter]
             passes, per_kernel = per_pass(rows, lambda r: float(r["Counter_Value"]))
             if passes:
                 pmc[counter] = {"per_pass": sum(passes) / len(passes), "passes": len(passes), "per_pass_by_kernel": per_kernel}
         if "SQ_INSTS_VALU" in pmc:
-            # the second roofline of bench.py: wave-level VALU instructions against 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles
+            # the second roofline of bench.py: wave-level VALU instructions of a pass against the MEASURED issue peak
+            peak, peak_source = measured_valu_peak()
             json.dump({"workload": workload, "n_gpus": 1, "passes_profiled": pmc["SQ_INSTS_VALU"]["passes"],
                        "valu_wave_insts_per_launch": pmc["SQ_INSTS_VALU"]["per_pass"],
                        "by_kernel": pmc["SQ_INSTS_VALU"]["per_pass_by_kernel"],
-                       "issue_peak_wave_insts_per_s": 256 * 4 * 2.4e9 / 4,
+                       "issue_peak_wave_insts_per_s": peak, "issue_peak_source": peak_source,
                        "source": "rocprofv3 --pmc SQ_INSTS_VALU (profiles/collect.sh %s), summed over the kernels of a pass; profiles/%s_pmc.json" % (tag, tag)},
                       open(os.path.join(ROOT, "profiles", "valu_insts.json"), "w"), indent=1)
+    # where the wave-cycles go, per kernel: ACTIVE (issuing) / WAIT_INST_ANY (ready, waiting to issue) / WAIT_ANY (parked on s_waitcnt)
+    f = glob.glob(os.path.join(base, f"{tag}_wait", "*", "*_counter_collection.csv"))
+    if f:
+        agg = {}
+        for r in csv.DictReader(open(f[0])):
+            if "pt_" not in r["Kernel_Name"]:
+                continue
+            agg.setdefault(short(r["Kernel_Name"]), {}).setdefault(r["Counter_Name"], 0.0)
+            agg[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
+        waits = {}
+        for k, v in agg.items():
+            wc = v.get("SQ_WAVE_CYCLES", 0.0)
+            if wc <= 0:
+                continue
+            waits[k] = {"wave_quad_cycles": wc, "waves": v.get("SQ_WAVES", 0.0), "valu_insts": v.get("SQ_INSTS_VALU", 0.0),
+                        "frac_active_valu": v.get("SQ_ACTIVE_INST_VALU", 0.0) / wc, "frac_active_any": v.get("SQ_ACTIVE_INST_ANY", 0.0) / wc,
+                        "frac_wait_issue": v.get("SQ_WAIT_INST_ANY", 0.0) / wc, "frac_wait_memory": v.get("SQ_WAIT_ANY", 0.0) / wc}
+        pmc["wave_cycle_breakdown"] = {"by_kernel": waits, "note": "SQ_* in quad-cycles; ACTIVE_INST_ANY + WAIT_INST_ANY + WAIT_ANY ~ WAVE_CYCLES (profiled passes run serialised)"}
     out["pmc"] = pmc
     if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
         fetch = pmc["FETCH_SIZE"]["KiB_per_pass"] * 1024
@@ -99,8 +128,9 @@ def main():
         out["hbm_bytes_per_pass"] = {"fetch_raw": fetch, "fetch_x2_upper": 2 * fetch, "write": write,
                                      "total_raw": fetch + write, "total_upper": 2 * fetch + write}
         json.dump({"workload": workload, "n_gpus": 1, "bytes_per_launch": round(2 * fetch + write),
+                   "source": "profiles/%s_pmc.json" % tag,
                    "note": "per pass (all kernels of the schedule): FETCH_SIZE x2 (gfx950 correction; upper estimate for scattered 16-B reads) "
-                           "+ WRITE_SIZE, separate --pmc passes; source profiles/%s_pmc.json" % tag},
+                           "+ WRITE_SIZE, separate rocprofv3 --pmc passes (profiles/collect.sh %s)" % tag},
                   open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
     json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
