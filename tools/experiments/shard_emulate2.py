@@ -5,7 +5,7 @@ from unity_webgpu_pathtracer_amd.pathtracer import PathTracer
 s = scenes.make_scene("sponza", tex_size=1024)
 W,H=1920,1080
 def seed_of(k): return (0x12345678 + k*0x9E3779B9) & 0xFFFFFFFF
-K=8
+K=16
 for world in (2, 4, 8):
     for sched in (1,):
         pt = PathTracer(s, width=W, height=H, samplesPerPass=8, rank=0, world_size=world, schedule=sched)
