@@ -13,4 +13,12 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/${TA
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d gpurun_out/${TAG}_valu -- $CMD > gpurun_out/${TAG}_valu.log 2>&1
 # where the wave-cycles go: WAIT_ANY (parked on s_waitcnt) + WAIT_INST_ANY (issue stall) + ACTIVE_INST_ANY ~ WAVE_CYCLES (quad-cycles)
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU --kernel-trace --output-format csv -d gpurun_out/${TAG}_wait -- $CMD > gpurun_out/${TAG}_wait.log 2>&1
+# the vector-memory path and the dispatcher (one block's counters per pass: TA and TD hold two each, rocprofv3 aborts on more)
+for G in "ta:TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum" "td:TD_TD_BUSY_sum TD_TC_STALL_sum" \
+         "tcp:TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum" \
+         "tcc:TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "grbm:GRBM_GUI_ACTIVE" \
+         "spi:SPI_RA_TMP_STALL_CSN SPI_RA_WAVE_SIMD_FULL_CSN SPI_RA_VGPR_SIMD_FULL_CSN SPI_RA_LDS_CU_FULL_CSN"; do
+  NAME=${G%%:*}; COUNTERS=${G#*:}
+  timeout -k 10 200 rocprofv3 --pmc $COUNTERS --kernel-trace --output-format csv -d gpurun_out/${TAG}_$NAME -- $CMD > gpurun_out/${TAG}_$NAME.log 2>&1 || echo "pass $NAME failed"
+done
 tail -1 gpurun_out/${TAG}_trace.log | cut -c1-600

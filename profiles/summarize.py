@@ -121,6 +121,33 @@ def main():
                         "frac_active_valu": v.get("SQ_ACTIVE_INST_VALU", 0.0) / wc, "frac_active_any": v.get("SQ_ACTIVE_INST_ANY", 0.0) / wc,
                         "frac_wait_issue": v.get("SQ_WAIT_INST_ANY", 0.0) / wc, "frac_wait_memory": v.get("SQ_WAIT_ANY", 0.0) / wc}
         pmc["wave_cycle_breakdown"] = {"by_kernel": waits, "note": "SQ_* in quad-cycles; ACTIVE_INST_ANY + WAIT_INST_ANY + WAIT_ANY ~ WAVE_CYCLES (profiled passes run serialised)"}
+    # vector-memory path, L2 and dispatcher counters, summed per kernel over the profiled passes (one rocprofv3 run per block)
+    mem = {}
+    for name in ("ta", "td", "tcp", "tcc", "grbm", "spi"):
+        f = glob.glob(os.path.join(base, f"{tag}_{name}", "*", "*_counter_collection.csv"))
+        if not f:
+            continue
+        for r in csv.DictReader(open(f[0])):
+            if "pt_" not in r["Kernel_Name"]:
+                continue
+            k = short(r["Kernel_Name"])
+            mem.setdefault(k, {}).setdefault(r["Counter_Name"], 0.0)
+            mem[k][r["Counter_Name"]] += float(r["Counter_Value"])
+    for k, v in mem.items():
+        cu_cycles = v.get("GRBM_GUI_ACTIVE", 0.0) / 8.0 * 256.0          # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 256 CUs
+        if cu_cycles > 0:
+            if "TA_TA_BUSY_sum" in v:
+                v["ta_busy_frac"] = v["TA_TA_BUSY_sum"] / cu_cycles
+            if "TD_TD_BUSY_sum" in v:
+                v["td_busy_frac"] = v["TD_TD_BUSY_sum"] / cu_cycles
+        if v.get("TCP_TCC_READ_REQ_sum"):
+            v["tcp_to_l2_read_latency_cycles"] = v.get("TCP_TCC_READ_REQ_LATENCY_sum", 0.0) / v["TCP_TCC_READ_REQ_sum"]
+        if v.get("TCC_HIT_sum") is not None and (v.get("TCC_HIT_sum", 0) + v.get("TCC_MISS_sum", 0)) > 0:
+            v["l2_hit_rate"] = v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
+        if v.get("TA_FLAT_READ_WAVEFRONTS_sum") and v.get("TD_TD_BUSY_sum"):
+            v["td_cycles_per_vector_load"] = v["TD_TD_BUSY_sum"] / v["TA_FLAT_READ_WAVEFRONTS_sum"]
+    if mem:
+        pmc["memory_path_and_dispatch"] = {"by_kernel": mem, "note": "sums over the profiled passes (passes run serialised under --pmc); *_frac against GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs"}
     out["pmc"] = pmc
     if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
         fetch = pmc["FETCH_SIZE"]["KiB_per_pass"] * 1024
