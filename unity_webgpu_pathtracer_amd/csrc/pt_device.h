@@ -260,6 +260,10 @@ PT_DEV void intersect_triangle(const float4* __restrict__ tris, uint32_t triAddr
     // (left to itself hipcc sinks the v0 load under the determinant test: two dependent round trips)
     float4 t0 = tris[triAddr + 0], t1 = tris[triAddr + 1], t2 = tris[triAddr + 2];
     asm volatile("" : "+v"(t0.x), "+v"(t1.x), "+v"(t2.x), "+v"(t2.w));
+#ifdef PT_EXP_TRI_EXTRA_VALU
+#pragma unroll
+    for (int i = 0; i < PT_EXP_TRI_EXTRA_VALU; ++i) asm volatile("v_mov_b32 %0, %0" : "+v"(t0.x));       // EXPERIMENT: sensitivity to triangle-block VALU
+#endif
     intersect_triangle_rows<false>(t0, t1, t2, 0u, o, d, hit);
 }
 

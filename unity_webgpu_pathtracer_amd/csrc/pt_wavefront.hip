@@ -207,9 +207,11 @@ PT_DEV bool ray_exists(uint32_t f, uint32_t kind)
 #ifndef PT_WF_TAIL_GROUP
 #define PT_WF_TAIL_GROUP 8u     // source waves per tail wave
 #endif
-#define PT_WF_SUSP_ROWS 6u      // uint4 rows per record
+#define PT_WF_SUSP_STACK_ROWS ((PT_WF_LDS_STACK + 1u) / 2u)       // two stack entries per uint4 row
+#define PT_WF_SUSP_ROWS (2u + PT_WF_SUSP_STACK_ROWS)             // uint4 rows per record (6 = 96 bytes with the default 8-entry LDS stack)
+static_assert(PT_WF_SUSP_ROWS <= 6u, "pt_api.hip sizes the record array for 6 rows per record");
 
-#if PT_WF_SUSPEND > 0
+// A record holds the LDS part of the stack; a ray whose stack reaches into the HBM slab is not suspended (it is finished first).
 template <class ST>
 PT_DEV void suspend_ray(const PTWfBuffers& B, uint32_t rec, uint32_t slot, uint32_t kind, const RayState& r, ST& st)
 {
@@ -217,17 +219,12 @@ PT_DEV void suspend_ray(const PTWfBuffers& B, uint32_t rec, uint32_t slot, uint3
     p[0] = make_uint4(slot | (kind << 30), r.sp | (r.overflow ? 0x100u : 0u), r.ng.x, r.ng.y);
     p[1] = make_uint4(r.tg.x, r.tg.y, pt_asuint(r.hit.t), 0u);
 #pragma unroll
-    for (uint32_t e = 0; e < 4u; ++e) {
-        const uint2 x = st.lds[(2u * e) * st.stride], y = st.lds[(2u * e + 1u) * st.stride];
+    for (uint32_t e = 0; e < PT_WF_SUSP_STACK_ROWS; ++e) {
+        const uint2 x = st.lds[(2u * e) * st.stride];
+        const uint2 y = (2u * e + 1u < PT_WF_LDS_STACK) ? st.lds[(2u * e + 1u) * st.stride] : make_uint2(0u, 0u);
         p[2u + e] = make_uint4(x.x, x.y, y.x, y.y);
     }
 }
-#else
-template <class ST> PT_DEV void suspend_ray(const PTWfBuffers&, uint32_t, uint32_t, uint32_t, const RayState&, ST&) {}
-#endif
-#if PT_WF_SUSPEND > 0
-static_assert(PT_WF_LDS_STACK == 8, "a suspension record holds the eight LDS stack entries");
-#endif
 
 template <bool STATS, bool TAIL>
 __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(DScene S, PTWfBuffers B)
@@ -320,7 +317,10 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(
                 const uint32_t take = nIdle < left ? nIdle : left;
                 if (!have && rankI < take) {
                     const uint4* p = B.susp + (size_t)xchg[cursor + rankI] * PT_WF_SUSP_ROWS;
-                    const uint4 a = p[0], b = p[1], e0 = p[2], e1 = p[3], e2 = p[4], e3 = p[5];
+                    const uint4 a = p[0], b = p[1];
+                    uint4 er[PT_WF_SUSP_STACK_ROWS];
+#pragma unroll
+                    for (uint32_t e = 0; e < PT_WF_SUSP_STACK_ROWS; ++e) er[e] = p[2u + e];
                     mySlot = a.x & 0x3FFFFFFFu;
                     myKind = a.x >> 30;
                     v3 o, d;
@@ -332,10 +332,11 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(
                     rs.ng = make_uint2(a.z, a.w);
                     rs.tg = make_uint2(b.x, b.y);
                     rs.hit.t = pt_asfloat(b.z);
-                    st.lds[0u * 64u] = make_uint2(e0.x, e0.y); st.lds[1u * 64u] = make_uint2(e0.z, e0.w);
-                    st.lds[2u * 64u] = make_uint2(e1.x, e1.y); st.lds[3u * 64u] = make_uint2(e1.z, e1.w);
-                    st.lds[4u * 64u] = make_uint2(e2.x, e2.y); st.lds[5u * 64u] = make_uint2(e2.z, e2.w);
-                    st.lds[6u * 64u] = make_uint2(e3.x, e3.y); st.lds[7u * 64u] = make_uint2(e3.z, e3.w);
+#pragma unroll
+                    for (uint32_t e = 0; e < PT_WF_SUSP_STACK_ROWS; ++e) {
+                        st.lds[(2u * e) * 64u] = make_uint2(er[e].x, er[e].y);
+                        if (2u * e + 1u < PT_WF_LDS_STACK) st.lds[(2u * e + 1u) * 64u] = make_uint2(er[e].z, er[e].w);
+                    }
                     have = true;
                 }
                 cursor += take;
