@@ -51,6 +51,28 @@ __global__ __launch_bounds__(256) void k_dep(float* out, float b, float c)
     if (a == 12345.678f) { lds[threadIdx.x] = a; out[blockIdx.x * 256 + threadIdx.x] = lds[(threadIdx.x + 1) & 255]; }
 }
 
+// 8 independent register PAIRS, v_pk_fma_f32 (two fp32 FMAs per lane per instruction): does the packed form issue at the
+// plain rate (= 2x the flops) or at half of it?
+__global__ __launch_bounds__(256) void k_pk(float* out, float b, float c)
+{
+    extern __shared__ float lds[];
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 a[8];
+    const f2 bb = {b, b}, cc = {c, c};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = f2{(float)(threadIdx.x + i), (float)(threadIdx.x + 2 * i)};
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+        for (int r = 0; r < PER_ITER / 8; ++r)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(bb), "v"(cc));
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += a[i].x + a[i].y;
+    if (s == 12345.678f) { lds[threadIdx.x] = s; out[blockIdx.x * 256 + threadIdx.x] = lds[(threadIdx.x + 1) & 255]; }
+}
+
 // the traversal's own mix: v_cvt_f32_ubyteN + v_fma_f32 + v_max/min (independent per "child"), 6 cvt + 6 fma + 4 minmax per group
 __global__ __launch_bounds__(256) void k_mix(float* out, float b, float c, unsigned q)
 {
@@ -92,14 +114,14 @@ int main()
     CHECK(hipMalloc(&out, 64u << 20));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    printf("{\"device\": \"%s\", \"cus\": %d, \"clock_mhz_max\": %d, \"iters\": %d, \"valu_per_iter\": {\"indep\": %d, \"dep\": %d, \"mix\": %d},\n \"results\": [\n",
-           prop.gcnArchName, cus, prop.clockRate / 1000, ITERS, PER_ITER, PER_ITER, 4 * 18);
-    const char* names[3] = {"indep", "dep", "mix"};
+    printf("{\"device\": \"%s\", \"cus\": %d, \"clock_mhz_max\": %d, \"iters\": %d, \"valu_per_iter\": {\"indep\": %d, \"dep\": %d, \"mix\": %d, \"pk\": %d},\n \"results\": [\n",
+           prop.gcnArchName, cus, prop.clockRate / 1000, ITERS, PER_ITER, PER_ITER, 4 * 18, PER_ITER);
+    const char* names[4] = {"indep", "dep", "mix", "pk_fma"};
     bool first = true;
-    for (int kind = 0; kind < 3; ++kind) {
+    for (int kind = 0; kind < 4; ++kind) {
         for (int w : {1, 2, 4, 8}) {
             const size_t ldsBytes = (160u * 1024u) / w;
-            const void* fn = kind == 0 ? (const void*)k_indep : kind == 1 ? (const void*)k_dep : (const void*)k_mix;
+            const void* fn = kind == 0 ? (const void*)k_indep : kind == 1 ? (const void*)k_dep : kind == 2 ? (const void*)k_mix : (const void*)k_pk;
             CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
             const int blocks = 16 * cus * w;
             double best = 1e30;
@@ -107,6 +129,7 @@ int main()
                 CHECK(hipEventRecord(e0, 0));
                 if (kind == 0) hipLaunchKernelGGL(k_indep, dim3(blocks), dim3(256), ldsBytes, 0, out, 1.0000001f, 1e-9f);
                 else if (kind == 1) hipLaunchKernelGGL(k_dep, dim3(blocks), dim3(256), ldsBytes, 0, out, 1.0000001f, 1e-9f);
+                else if (kind == 3) hipLaunchKernelGGL(k_pk, dim3(blocks), dim3(256), ldsBytes, 0, out, 1.0000001f, 1e-9f);
                 else hipLaunchKernelGGL(k_mix, dim3(blocks), dim3(256), ldsBytes, 0, out, 1.0000001f, 1e-9f, 0x01020304u);
                 CHECK(hipEventRecord(e1, 0));
                 CHECK(hipEventSynchronize(e1));

@@ -143,8 +143,10 @@ int ensure_wavefront(PTContext* c, PTContext::WfSet& set, uint32_t numSlots, uin
     PTWfBuffers& B = set.wf;
     B.flags = (uint32_t*)carve(n * 4);
     B.rng = (uint32_t*)carve(n * 4);
-    float4** arrs[13] = {&B.ro, &B.rd, &B.rad, &B.thr, &B.color, &B.neeO, &B.envD, &B.lightD, &B.envC, &B.lightC, &B.pthr, &B.hit, &B.hit2};
+    float4** arrs[PT_F4_COUNT] = {&B.ro, &B.rd, &B.rad, &B.thr, &B.color, &B.neeO, &B.envD, &B.lightD, &B.envC, &B.lightC, &B.pthr, &B.hit, &B.hit2};   // PT_F4_* order
     for (auto a : arrs) *a = (float4*)carve(n * 16);
+    B.f4base = B.ro;
+    B.f4stride = (uint32_t)(align(n * 16) / 16);
     B.occl = (uint8_t*)carve(n * 2);
     B.aliveFlags = (uint32_t*)carve((size_t)maxIterations * 4);
     B.statRows = (unsigned long long*)carve((size_t)numRows * 16 * 8);

@@ -144,8 +144,8 @@ typedef TravStackT<PT_LDS_STACK> TravStack;
 // path lives in a register across the traversal loop, where at 64 VGPRs it would be spilled -- to scratch.
 PT_DEV size_t spill_row(pt_lds_word gwave)
 {
-    uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    asm volatile("" : "+v"(lane));
+    uint32_t lane;              // volatile asm: the two instructions stay HERE (as builtins they are hoisted out of the loop and spilled)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
     return (size_t)(*gwave * 64u + lane);
 }
 
@@ -1594,4 +1594,41 @@ PT_DEV bool ray_unistep(const DScene& S, RayState& r, ST& st, Counters& cn)
     }
     if (finished && STATS && r.overflow) cn.overflows++;
     return finished;
+}
+
+// The two halves of ray_unistep as separate phases, so that a wave can decide per iteration WHICH phase to run: the triangle
+// block costs ~100 VALU instructions per execution whatever the number of lanes in it, so lanes whose node visit produced
+// triangles PARK until enough of them have accumulated (pt_wavefront.hip, PT_WF_TRI_PARK).  A lane's own sequence of operations
+// -- hence every result and counter -- is unchanged: it only waits.
+template <bool STATS>
+PT_DEV bool ray_tri_one(const DScene& S, RayState& r, Counters& cn)                 // precondition: r.tg.y != 0
+{
+    const uint32_t triangleIndex = 31u - (uint32_t)__clz((int)r.tg.y);
+    intersect_triangle(S.tris, r.tg.x + triangleIndex * 3u, r.o, r.d, r.hit);
+    if (STATS) cn.triTests++;
+    r.tg.y -= 1u << triangleIndex;
+    if (r.anyHit && r.hit.t < PT_FAR_PLANE) {
+        if (STATS && r.overflow) cn.overflows++;
+        return true;
+    }
+    return false;
+}
+
+template <bool STATS, class ST>
+PT_DEV bool ray_node_one(const DScene& S, RayState& r, ST& st, Counters& cn)        // precondition: r.tg.y == 0
+{
+    if (r.ng.y <= 0x00FFFFFFu) {
+        if (r.sp > 0u) { --r.sp; r.ng = stack_pop(st, r.sp); }
+        else {
+            if (STATS && r.overflow) cn.overflows++;
+            return true;
+        }
+    }
+    if (r.ng.y > 0x00FFFFFFu) {
+        cwbvh_visit_node<STATS>(S.nodes, 0u, r.o, r.invDir, r.octinv4, r.hit.t, r.ng, r.tg, r.sp, r.overflow, st, cn);
+    } else {
+        r.tg = r.ng;
+        r.ng = make_uint2(0u, 0u);
+    }
+    return false;
 }

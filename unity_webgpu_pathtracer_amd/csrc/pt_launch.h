@@ -58,6 +58,8 @@ hipError_t pt_launch_copy_texture(const float4* dTexture, uint32_t width, uint32
 hipError_t pt_launch_present(const PTPresentParams& Q, const float4* src, float4* dst, hipStream_t stream);
 
 // ---- schedule 1 (wavefront): slot-indexed path state in HBM (see pt_wavefront.hip) ----
+enum : uint32_t { PT_F4_RO = 0, PT_F4_RD, PT_F4_RAD, PT_F4_THR, PT_F4_COLOR, PT_F4_NEEO, PT_F4_ENVD, PT_F4_LIGHTD, PT_F4_ENVC, PT_F4_LIGHTC,
+                  PT_F4_PTHR, PT_F4_HIT, PT_F4_HIT2, PT_F4_COUNT };
 #ifndef PT_WF_LDS_STACK
 #define PT_WF_LDS_STACK 8       // traversal-stack entries per lane kept in LDS by the refill / persistent trace kernels; deeper ones go to stackSpill
 #endif
@@ -70,6 +72,11 @@ struct PTWfBuffers {
     float4 *envC, *lightC, *pthr;        // their contributions and the throughput they apply to
     float4* hit;                // [numSlots] (t, u, v, triIndex bits) written by trace kind 0
     float4* hit2;               // [numSlots] HAS_TLAS only: (world hit position, instance index bits)
+    // The thirteen float4 arrays above are carved back to back at a fixed stride: array k starts at f4base + k * f4stride
+    // (order: PT_F4_*).  The trace kernels address them this way -- one base pointer instead of seven -- because at 8 waves/SIMD a
+    // wave may hold 80 SGPRs, and every pointer costs two.
+    float4* f4base;
+    uint32_t f4stride;          // in float4 elements
     uint8_t* occl;              // [2][numSlots] written by trace kinds 1, 2
     uint2* stackSpill;          // [numSlots][32 - PT_WF_LDS_STACK]: traversal-stack entries beyond the LDS part (refill / persistent trace kernels)
     uint32_t* tlasSpill;        // [numSlots][32]: HAS_TLAS refill kernel, TLAS-stack entries beyond its LDS part (allocated for HAS_TLAS scenes only)

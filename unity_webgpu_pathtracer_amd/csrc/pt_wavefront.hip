@@ -165,11 +165,30 @@ static_assert(PT_WF_RANGE >= 64u && (PT_WF_RANGE & (PT_WF_RANGE - 1u)) == 0u,
 #ifndef PT_WF_FLAT
 #define PT_WF_FLAT 0            // 0: ray_step (node visit + all its triangles per wave iteration), 2: ray_unistep (one triangle OR one node visit, one memory round trip)
 #endif
+#ifndef PT_WF_TRI_PARK
+#define PT_WF_TRI_PARK 4u       // > 0: two-phase wave iteration (ray_tri_one / ray_node_one); lanes with triangles pending wait until
+                                // that many lanes do.  0: ray_step's nested loops.  2 ... 12 measure the same (+6 %), 16: +3 %, 24: -2 %
+#endif
 #if PT_WF_FLAT == 2
 #define PT_WF_STEP ray_unistep
 #else
 #define PT_WF_STEP ray_step
 #endif
+
+// number of set bits of a wave mask below this lane (v_mbcnt: no per-lane 64-bit "lanes below me" mask to keep in registers)
+PT_DEV uint32_t rank_below(unsigned long long m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// float4 state array k of the set (pt_launch.h PT_F4_*), addressed from ONE base pointer
+PT_DEV float4* f4_array(const PTWfBuffers& B, uint32_t k) { return B.f4base + (size_t)k * B.f4stride; }
+// the ray of (slot, kind): bounce ray (ro, rd), environment NEE (neeO, envD) or light NEE (neeO, lightD)
+PT_DEV void fetch_ray(const PTWfBuffers& B, uint32_t slot, uint32_t kind, v3& o, v3& d)
+{
+    o = xyz(f4_array(B, kind == 0u ? PT_F4_RO : PT_F4_NEEO)[slot]);
+    d = xyz(f4_array(B, kind == 0u ? PT_F4_RD : (kind == 1u ? PT_F4_ENVD : PT_F4_LIGHTD))[slot]);
+}
 
 // Result stores of the trace kernels.  The empty asm pins the address arithmetic (and the constant miss record) to the
 // store instead of letting it be hoisted into registers that live across the whole traversal loop (64-VGPR budget).
@@ -177,7 +196,7 @@ PT_DEV void store_miss(const PTWfBuffers& B, uint32_t slot)
 {
     float far = PT_FAR_PLANE;
     asm volatile("" : "+v"(far), "+v"(slot));
-    B.hit[slot] = make_float4(far, 0.0f, 0.0f, 0.0f);
+    f4_array(B, PT_F4_HIT)[slot] = make_float4(far, 0.0f, 0.0f, 0.0f);
 }
 PT_DEV void store_occlusion(const PTWfBuffers& B, uint32_t kind, uint32_t slot, bool occluded)
 {
@@ -238,7 +257,6 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(
     const uint32_t gw = blockIdx.x;
     const uint32_t numWaves = (B.numSlots + PT_WF_RANGE - 1u) / PT_WF_RANGE;
     const uint32_t slotBase = gw * PT_WF_RANGE;
-    const unsigned long long ltMask = (1ull << lane) - 1ull;
     volatile uint32_t* xchg = s_xchg;
     if (lane == 0u) s_gw = gw;
 
@@ -281,7 +299,7 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(
         // ---- refill: compact the next candidates into the idle lanes
         while (cursor < nItems && (nIdle >= PT_WF_REFILL || nIdle == 64u)) {
             const unsigned long long idle = __ballot(!have);
-            const uint32_t rankI = (uint32_t)__popcll(idle & ltMask);
+            const uint32_t rankI = rank_below(idle);
             if (!TAIL) {
                 const uint32_t item = cursor + lane;
                 const uint32_t kind = item / PT_WF_RANGE;
@@ -291,7 +309,7 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(
                 const unsigned long long V = __ballot(valid);
                 const uint32_t nV = (uint32_t)__popcll(V);
                 const uint32_t take = nIdle < nV ? nIdle : nV;
-                const uint32_t rankV = (uint32_t)__popcll(V & ltMask);
+                const uint32_t rankV = rank_below(V);
                 uint32_t consumed = 64u;
                 if (take < nV) consumed = (uint32_t)__ffsll((long long)__ballot(valid && rankV == take)) - 1u;   // first ray NOT taken
                 if (valid && rankV < take) xchg[rankV] = item;
@@ -301,8 +319,7 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(
                     myKind = it / PT_WF_RANGE;
                     mySlot = slotBase + (it & (PT_WF_RANGE - 1u));
                     v3 o, d;
-                    if (myKind == 0u) { o = xyz(B.ro[mySlot]); d = xyz(B.rd[mySlot]); }
-                    else { o = xyz(B.neeO[mySlot]); d = xyz(myKind == 1u ? B.envD[mySlot] : B.lightD[mySlot]); }
+                    fetch_ray(B, mySlot, myKind, o, d);
                     if (myKind == 0u) cn.closestRays++; else cn.shadowRays++;
                     if (ray_begin(rs, o, d, myKind != 0u)) {
                         // NaN ray: certain miss
@@ -324,8 +341,7 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(
                     mySlot = a.x & 0x3FFFFFFFu;
                     myKind = a.x >> 30;
                     v3 o, d;
-                    if (myKind == 0u) { o = xyz(B.ro[mySlot]); d = xyz(B.rd[mySlot]); }
-                    else { o = xyz(B.neeO[mySlot]); d = xyz(myKind == 1u ? B.envD[mySlot] : B.lightD[mySlot]); }
+                    fetch_ray(B, mySlot, myKind, o, d);
                     ray_begin(rs, o, d, myKind != 0u);                // same invDir / octinv4 as when the ray started
                     rs.sp = a.y & 0xFFu;
                     rs.overflow = (a.y & 0x100u) != 0u;
@@ -362,18 +378,44 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(
                 }
             }
 #endif
-            if (have) {
-                // the hit record goes to memory whenever a step improved it, so (u, v, triIndex) need no registers across
-                // iterations (64 VGPRs without a spill = no scratch, see TravStackT); a ray that never hits writes the miss
-                const float tBefore = rs.hit.t;
-                const bool fin = PT_WF_STEP<STATS>(S, rs, st, cn);
-                if (myKind == 0u && rs.hit.t < tBefore) B.hit[mySlot] = make_float4(rs.hit.t, rs.hit.u, rs.hit.v, pt_asfloat(rs.hit.triIndex));
+#if PT_WF_TRI_PARK > 0
+            // Two phases per wave iteration instead of ray_step's nested loops: (1) every lane with a triangle pending tests ONE
+            // (the block runs when PT_WF_TRI_PARK lanes want it, or when nobody can do anything else), (2) every lane without a
+            // triangle pending -- including those that have just tested their last one -- pops and visits its next node.  A lane
+            // with k triangles spends k - 1 extra iterations in phase 1 while its neighbours keep visiting nodes; the triangle
+            // block runs once per iteration at ~3x the lane utilisation of the nested loop (2.1 executions at 8 %).
+            {
+                const bool wantTri = have && rs.tg.y != 0u;
+                const uint32_t nT = (uint32_t)__popcll(__ballot(wantTri));
+                const uint32_t nN = (uint32_t)__popcll(__ballot(have && !wantTri));
+                bool fin = false;
+                if ((nT >= PT_WF_TRI_PARK || nN == 0u) && wantTri) {
+                    const float tBefore = rs.hit.t;
+                    fin = ray_tri_one<STATS>(S, rs, cn);
+                    // the hit record goes to memory when a test improved it: (u, v, triIndex) need no registers across iterations
+                    if (myKind == 0u && rs.hit.t < tBefore) f4_array(B, PT_F4_HIT)[mySlot] = make_float4(rs.hit.t, rs.hit.u, rs.hit.v, pt_asfloat(rs.hit.triIndex));
+                }
+                if (have && !fin && rs.tg.y == 0u) fin = ray_node_one<STATS>(S, rs, st, cn);
                 if (fin) {
                     if (myKind == 0u) { if (!(rs.hit.t < PT_FAR_PLANE)) store_miss(B, mySlot); }
                     else store_occlusion(B, myKind, mySlot, rs.hit.t < PT_FAR_PLANE);
                     have = false;
                 }
             }
+#else
+            if (have) {
+                // the hit record goes to memory whenever a step improved it, so (u, v, triIndex) need no registers across
+                // iterations (64 VGPRs without a spill = no scratch, see TravStackT); a ray that never hits writes the miss
+                const float tBefore = rs.hit.t;
+                const bool fin = PT_WF_STEP<STATS>(S, rs, st, cn);
+                if (myKind == 0u && rs.hit.t < tBefore) f4_array(B, PT_F4_HIT)[mySlot] = make_float4(rs.hit.t, rs.hit.u, rs.hit.v, pt_asfloat(rs.hit.triIndex));
+                if (fin) {
+                    if (myKind == 0u) { if (!(rs.hit.t < PT_FAR_PLANE)) store_miss(B, mySlot); }
+                    else store_occlusion(B, myKind, mySlot, rs.hit.t < PT_FAR_PLANE);
+                    have = false;
+                }
+            }
+#endif
             nIdle = (uint32_t)__popcll(__ballot(!have));
         }
         if (!TAIL && PT_WF_SUSPEND > 0u && exhausted && nIdle < 64u) {
@@ -382,8 +424,13 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(
                 while (__ballot(have && rs.sp > PT_WF_LDS_STACK) != 0ull) {
                     if (have) {
                         const float tBefore = rs.hit.t;
+#if PT_WF_TRI_PARK > 0
+                        // a lane may arrive with triangles pending: one triangle OR one node visit, whichever is next for it
+                        const bool fin = rs.tg.y != 0u ? ray_tri_one<STATS>(S, rs, cn) : ray_node_one<STATS>(S, rs, st, cn);
+#else
                         const bool fin = PT_WF_STEP<STATS>(S, rs, st, cn);
-                        if (myKind == 0u && rs.hit.t < tBefore) B.hit[mySlot] = make_float4(rs.hit.t, rs.hit.u, rs.hit.v, pt_asfloat(rs.hit.triIndex));
+#endif
+                        if (myKind == 0u && rs.hit.t < tBefore) f4_array(B, PT_F4_HIT)[mySlot] = make_float4(rs.hit.t, rs.hit.u, rs.hit.v, pt_asfloat(rs.hit.triIndex));
                         if (fin) {
                             if (myKind == 0u) { if (!(rs.hit.t < PT_FAR_PLANE)) store_miss(B, mySlot); }
                             else store_occlusion(B, myKind, mySlot, rs.hit.t < PT_FAR_PLANE);
@@ -393,7 +440,7 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(
                 }
             }
             const unsigned long long act = __ballot(have);
-            if (have) suspend_ray(B, *PT_LDS_WORD(s_gw) * PT_WF_SUSPEND + (uint32_t)__popcll(act & ltMask), mySlot, myKind, rs, st);
+            if (have) suspend_ray(B, *PT_LDS_WORD(s_gw) * PT_WF_SUSPEND + rank_below(act), mySlot, myKind, rs, st);
             have = false;
             nSuspended = (uint32_t)__popcll(act);
             break;
@@ -430,7 +477,6 @@ __global__ __launch_bounds__(64, PT_WF_TLAS_MIN_WAVES) void pt_wf_trace_refill_t
     const uint32_t lane = threadIdx.x;
     const uint32_t gw = blockIdx.x;
     const uint32_t slotBase = gw * PT_WF_RANGE;
-    const unsigned long long ltMask = (1ull << lane) - 1ull;
     volatile uint32_t* xchg = s_xchg;
     volatile uint32_t* tlds = &s_tstack[0][lane];
     if (lane == 0u) s_gw = gw;
@@ -467,7 +513,7 @@ __global__ __launch_bounds__(64, PT_WF_TLAS_MIN_WAVES) void pt_wf_trace_refill_t
         uint32_t nIdle = (uint32_t)__popcll(__ballot(!have));
         while (cursor < nItems && (nIdle >= PT_WF_REFILL || nIdle == 64u)) {
             const unsigned long long idle = __ballot(!have);
-            const uint32_t rankI = (uint32_t)__popcll(idle & ltMask);
+            const uint32_t rankI = rank_below(idle);
             const uint32_t item = cursor + lane;
             const uint32_t kind = item / PT_WF_RANGE;
             const uint32_t slot = slotBase + (item & (PT_WF_RANGE - 1u));
@@ -476,7 +522,7 @@ __global__ __launch_bounds__(64, PT_WF_TLAS_MIN_WAVES) void pt_wf_trace_refill_t
             const unsigned long long V = __ballot(valid);
             const uint32_t nV = (uint32_t)__popcll(V);
             const uint32_t take = nIdle < nV ? nIdle : nV;
-            const uint32_t rankV = (uint32_t)__popcll(V & ltMask);
+            const uint32_t rankV = rank_below(V);
             uint32_t consumed = 64u;
             if (take < nV) consumed = (uint32_t)__ffsll((long long)__ballot(valid && rankV == take)) - 1u;
             if (valid && rankV < take) xchg[rankV] = item;
@@ -486,8 +532,7 @@ __global__ __launch_bounds__(64, PT_WF_TLAS_MIN_WAVES) void pt_wf_trace_refill_t
                 myKind = it / PT_WF_RANGE;
                 mySlot = slotBase + (it & (PT_WF_RANGE - 1u));
                 v3 d;
-                if (myKind == 0u) { O = xyz(B.ro[mySlot]); d = xyz(B.rd[mySlot]); }
-                else { O = xyz(B.neeO[mySlot]); d = xyz(myKind == 1u ? B.envD[mySlot] : B.lightD[mySlot]); }
+                fetch_ray(B, mySlot, myKind, O, d);
                 if (myKind == 0u) cn.closestRays++; else cn.shadowRays++;
                 if (pt_isnan(O.x) || pt_isnan(O.y) || pt_isnan(O.z) || pt_isnan(d.x) || pt_isnan(d.y) || pt_isnan(d.z)) {
                     if (myKind == 0u) store_miss(B, mySlot);              // NaN ray: certain miss (traverse_tlas)
@@ -520,7 +565,7 @@ __global__ __launch_bounds__(64, PT_WF_TLAS_MIN_WAVES) void pt_wf_trace_refill_t
                         const float4 w0 = ip[4], w1 = ip[5], w2 = ip[6], w3 = ip[7], ints = ip[8];
                         if (STATS) cn.instanceVisits++;
                         nodeOffset = pt_asuint(ints.x); triOffset = pt_asuint(ints.y); attrOffset = pt_asuint(ints.z);
-                        const v3 wd = xyz(myKind == 0u ? B.rd[mySlot] : (myKind == 1u ? B.envD[mySlot] : B.lightD[mySlot]));
+                        const v3 wd = xyz(f4_array(B, myKind == 0u ? PT_F4_RD : (myKind == 1u ? PT_F4_ENVD : PT_F4_LIGHTD))[mySlot]);
                         const v4 lo4 = mul44c(w0, w1, w2, w3, v4{O.x, O.y, O.z, 1.0f});
                         const v4 ld4 = mul44c(w0, w1, w2, w3, v4{wd.x, wd.y, wd.z, 0.0f});
                         const float tKeep = rs.hit.t;
@@ -596,7 +641,7 @@ __global__ __launch_bounds__(64, PT_WF_TLAS_MIN_WAVES) void pt_wf_trace_refill_t
                         else blasDone = true;
                     }
                 }
-                if (myKind == 0u && rs.hit.t < tBefore) B.hit[mySlot] = make_float4(rs.hit.t, rs.hit.u, rs.hit.v, pt_asfloat(rs.hit.triIndex));
+                if (myKind == 0u && rs.hit.t < tBefore) f4_array(B, PT_F4_HIT)[mySlot] = make_float4(rs.hit.t, rs.hit.u, rs.hit.v, pt_asfloat(rs.hit.triIndex));
                 if (blasDone) {
                     if (STATS && rs.overflow) cn.overflows++;
                     inBlas = false;
@@ -611,8 +656,8 @@ __global__ __launch_bounds__(64, PT_WF_TLAS_MIN_WAVES) void pt_wf_trace_refill_t
                         const v4 wp = mul44c(l0, l1, l2, l3, v4{lp.x, lp.y, lp.z, 1.0f});
                         const v3 pos = mk3(wp.x, wp.y, wp.z);
                         rs.hit.t = length3(pos - O);
-                        ((float*)&B.hit[mySlot])[0] = rs.hit.t;
-                        B.hit2[mySlot] = make_float4(pos.x, pos.y, pos.z, pt_asfloat(instIndex));
+                        ((float*)&f4_array(B, PT_F4_HIT)[mySlot])[0] = rs.hit.t;
+                        f4_array(B, PT_F4_HIT2)[mySlot] = make_float4(pos.x, pos.y, pos.z, pt_asfloat(instIndex));
                     }
                 }
             }
@@ -659,7 +704,6 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_persist
     const uint32_t numChunks = (B.numSlots + PT_WF_CHUNK - 1u) / PT_WF_CHUNK;
     const uint32_t shard = blockIdx.x & (PT_WF_SHARDS - 1u);
     const uint32_t nItems = 3u * PT_WF_CHUNK;
-    const unsigned long long ltMask = (1ull << lane) - 1ull;
     volatile uint32_t* xchg = s_xchg;
 
     Counters cn = {};
@@ -696,19 +740,18 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_persist
             const unsigned long long V = __ballot(valid);
             const uint32_t nV = (uint32_t)__popcll(V);
             const uint32_t take = nIdle < nV ? nIdle : nV;
-            const uint32_t rankV = (uint32_t)__popcll(V & ltMask);
+            const uint32_t rankV = rank_below(V);
             uint32_t consumed = 64u;
             if (take < nV) consumed = (uint32_t)__ffsll((long long)__ballot(valid && rankV == take)) - 1u;
             if (valid && rankV < take) xchg[rankV] = item;
             __builtin_amdgcn_wave_barrier();
-            const uint32_t rankI = (uint32_t)__popcll(idle & ltMask);
+            const uint32_t rankI = rank_below(idle);
             if (!have && rankI < take) {
                 const uint32_t it = xchg[rankI];
                 myKind = it / PT_WF_CHUNK;
                 mySlot = slotBase + (it & (PT_WF_CHUNK - 1u));
                 v3 o, d;
-                if (myKind == 0u) { o = xyz(B.ro[mySlot]); d = xyz(B.rd[mySlot]); }
-                else { o = xyz(B.neeO[mySlot]); d = xyz(myKind == 1u ? B.envD[mySlot] : B.lightD[mySlot]); }
+                fetch_ray(B, mySlot, myKind, o, d);
                 if (myKind == 0u) cn.closestRays++; else cn.shadowRays++;
                 if (ray_begin(rs, o, d, myKind != 0u)) {
                     if (myKind == 0u) store_miss(B, mySlot);
@@ -725,7 +768,7 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_persist
             if (have) {
                 const float tBefore = rs.hit.t;
                 const bool fin = PT_WF_STEP<STATS>(S, rs, st, cn);
-                if (myKind == 0u && rs.hit.t < tBefore) B.hit[mySlot] = make_float4(rs.hit.t, rs.hit.u, rs.hit.v, pt_asfloat(rs.hit.triIndex));
+                if (myKind == 0u && rs.hit.t < tBefore) f4_array(B, PT_F4_HIT)[mySlot] = make_float4(rs.hit.t, rs.hit.u, rs.hit.v, pt_asfloat(rs.hit.triIndex));
                 if (fin) {
                     if (myKind == 0u) { if (!(rs.hit.t < PT_FAR_PLANE)) store_miss(B, mySlot); }
                     else store_occlusion(B, myKind, mySlot, rs.hit.t < PT_FAR_PLANE);
