@@ -1542,6 +1542,8 @@ float oracle_math(int fn, float x, float y)
         while (u < 0.0f) u += 1.0f;
         return u;
     }
+    case 14: return pt_unorm8((uint32_t)x);       // the kernels' form of a texel channel ...
+    case 15: return (float)((uint32_t)x & 0xFFu) / 255.0f;    // ... and the division of util/texture.hlsl that the oracle performs
     default: return 0.0f;
     }
 }

@@ -111,3 +111,13 @@ def test_texture_wrap_closed_form_equals_the_reference_loops(lib):
     assert np.array_equal(closed.view(np.uint32), loops.view(np.uint32))
     assert ((closed >= 0) & (closed <= 1)).all()
     assert np.isnan(lib.oracle_math(12, float("nan"), 0.0)) and np.isnan(lib.oracle_math(13, float("nan"), 0.0))
+
+
+def test_unorm8_equals_division_by_255_for_every_byte(lib):
+    """The kernels turn a texel channel into a float with pt_unorm8 (mul + 2 fma); the oracle divides by 255 as
+    util/texture.hlsl does.  All 256 inputs, bit for bit."""
+    b = np.arange(256, dtype=np.float32)
+    fast = _apply(lib, 14, b)
+    div = _apply(lib, 15, b)
+    assert np.array_equal(fast.view(np.uint32), div.view(np.uint32))
+    assert np.array_equal(div, (b / np.float32(255.0)).astype(np.float32))

@@ -57,7 +57,7 @@ struct RoctxRange {                      // the reference wraps its dispatch in 
 struct PTContext {
     int device = 0;
     hipStream_t stream = nullptr;
-    DeviceBuffer nodes, tris, attrs, materials, lights, tex, tlas, instances, envTex, envCdf;
+    DeviceBuffer nodes, tris, attrs, materials, lights, lightConst, tex, tlas, instances, envTex, envCdf;
     void* present = nullptr;                    // PTPresentToHost staging frame
     size_t presentBytes = 0;
     DScene scene = {};
@@ -422,7 +422,7 @@ PT_API int PTDestroy(PTContext* c)
     if (!c) return PT_OK;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
-    for (auto* b : {&c->nodes, &c->tris, &c->attrs, &c->materials, &c->lights, &c->tex, &c->tlas, &c->instances, &c->envTex, &c->envCdf}) if (b->ptr) hipFree(b->ptr);
+    for (auto* b : {&c->nodes, &c->tris, &c->attrs, &c->materials, &c->lights, &c->lightConst, &c->tex, &c->tlas, &c->instances, &c->envTex, &c->envCdf}) if (b->ptr) hipFree(b->ptr);
     for (int i = 0; i < 2; i++) if (c->frames[i]) hipFree(c->frames[i]);
     if (c->dStats) hipFree(c->dStats);
     if (c->present) hipFree(c->present);
@@ -494,6 +494,13 @@ PT_API int PTSetScene(PTContext* c, const PTSceneDesc* hostScene)
         if ((rc = upload(c, c->envTex, s->envTexture, n * 16))) return rc;
         if ((rc = upload(c, c->envCdf, cdf.data(), n * 4))) return rc;
     }
+    if (lights) {                                  // room for the per-light constants, filled below once the scene view is complete
+        DeviceBuffer& b = c->lightConst;
+        const size_t bytes = (size_t)s->lightCount * 64;
+        if (b.ptr && b.bytes < bytes) { hipFree(b.ptr); b.ptr = nullptr; b.bytes = 0; }
+        if (!b.ptr) { HIP_TRY(hipMalloc(&b.ptr, bytes)); b.bytes = bytes; }
+        b.used = bytes;
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));      // inputs are borrowed for the duration of the call only
     c->scene.nodes = (const uint4*)c->nodes.ptr;
     c->scene.tris = (const float4*)c->tris.ptr;
@@ -515,6 +522,11 @@ PT_API int PTSetScene(PTContext* c, const PTSceneDesc* hostScene)
     c->scene.envH = envOn ? (int32_t)s->envHeight : 0;
     c->scene.envCdfSum = cdfSum;
     c->scene.hasEnvTex = envOn ? 1u : 0u;
+    c->scene.lightConst = lights ? (const float4*)c->lightConst.ptr : nullptr;
+    if (lights) {
+        HIP_TRY(pt_launch_derive_lights(c->scene, (float4*)c->lightConst.ptr, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     c->hasScene = true;
     return PT_OK;
 }

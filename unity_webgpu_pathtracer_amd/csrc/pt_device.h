@@ -82,6 +82,7 @@ struct DScene {
     const float4* attrs;        // PTTriangleAttributes[] as 8 x float4
     const float4* materials;    // PTMaterialData[] as 8 x float4
     const float4* lights;       // PTLight[] as 4 x float4
+    const float4* lightConst;   // 4 x float4 per light: what the shader recomputes from the record at every use (derive_light_rows)
     const uint32_t* tex;        // TextureData
     int32_t lightCount;
     uint32_t materialCount;
@@ -573,6 +574,33 @@ PT_DEV DLight load_light(const DScene& S, int i)
     return l;
 }
 
+// Per-light constants.  The shader derives these from the light record at EVERY use (util/intersect.hlsl:30-53 per light per
+// closest hit, util/light.hlsl per light sample): a cross product, two normalisations and seven divisions whose operands
+// are scene constants -- ~115 VALU instructions per light per shading step, identical in all 64 lanes.  PTSetScene evaluates
+// the same expressions once per light with the same device code (pt_derive_lights), so every value is the one the per-call
+// evaluation would produce, bit for bit.
+//   row 0: N = normalize(cross(u, v)) (rectangle) / normalize(u) (spot), w = dot(N, position)
+//   row 1: u / dot(u, u)      row 2: v / dot(v, v)      row 3: normalize(N)  (the shader normalises the unit normal again)
+PT_DEV void derive_light_rows(const DLight& light, float4 rows[4])
+{
+    v3 n = mk3(0.0f), u = mk3(0.0f), v = mk3(0.0f), nn = mk3(0.0f);
+    float planeW = 0.0f;
+    if (light.type == PT_LIGHT_TYPE_RECTANGLE) {
+        n = normalize3(cross3(light.u, light.v));
+        planeW = dot3(n, light.position);
+        u = light.u / dot3(light.u, light.u);
+        v = light.v / dot3(light.v, light.v);
+        nn = normalize3(n);
+    } else if (light.type == PT_LIGHT_TYPE_SPOT) {
+        n = normalize3(light.u);
+        nn = normalize3(n);
+    }
+    rows[0] = make_float4(n.x, n.y, n.z, planeW);
+    rows[1] = make_float4(u.x, u.y, u.z, 0.0f);
+    rows[2] = make_float4(v.x, v.y, v.z, 0.0f);
+    rows[3] = make_float4(nn.x, nn.y, nn.z, 0.0f);
+}
+
 template <bool STATS>
 PT_DEV void intersect_lights(const DScene& S, v3 o, v3 d, SurfHit& hit, Counters& cn)
 {
@@ -581,10 +609,12 @@ PT_DEV void intersect_lights(const DScene& S, v3 o, v3 d, SurfHit& hit, Counters
         DLight light = load_light(S, i);
         if (STATS) cn.lightFetches++;
         if (light.type == PT_LIGHT_TYPE_RECTANGLE) {
-            v3 normal = normalize3(cross3(light.u, light.v));
-            float planeW = dot3(normal, light.position);
-            v3 u = light.u / dot3(light.u, light.u);
-            v3 v = light.v / dot3(light.v, light.v);
+            const float4* lc = S.lightConst + (size_t)i * 4;
+            const float4 c0 = lc[0], c1 = lc[1], c2 = lc[2];
+            v3 normal = mk3(c0.x, c0.y, c0.z);                   // normalize(cross(light.u, light.v))
+            float planeW = c0.w;                                 // dot(normal, light.position)
+            v3 u = mk3(c1.x, c1.y, c1.z);                        // light.u / dot(light.u, light.u)
+            v3 v = mk3(c2.x, c2.y, c2.z);                        // light.v / dot(light.v, light.v)
             // RectIntersect :6-27
             float dt = dot3(d, normal);
             float t = (planeW - dot3(normal, o)) / dt;
@@ -629,8 +659,7 @@ PT_DEV v4 texture_pixel(const DScene& S, uint32_t off, uint32_t width, uint32_t 
     y = y < height - 1u ? y : height - 1u;
     uint32_t p = S.tex[off + (y * width + x)];
     if (STATS) cn.texelFetches++;
-    return {(float)(p & 0xFFu) / 255.0f, (float)((p >> 8) & 0xFFu) / 255.0f,
-            (float)((p >> 16) & 0xFFu) / 255.0f, (float)((p >> 24) & 0xFFu) / 255.0f};
+    return {pt_unorm8(p), pt_unorm8(p >> 8), pt_unorm8(p >> 16), pt_unorm8(p >> 24)};    // == channel / 255.0f (include/ptmi_math.h)
 }
 
 template <bool STATS>
@@ -1155,10 +1184,11 @@ PT_DEV void nee_prepare_light(const DScene& S, v3 rayDir, const SurfHit& hit, co
     if (lightIndex > S.lightCount - 1) lightIndex = S.lightCount - 1;
     DLight light = load_light(S, lightIndex);
     if (STATS) cn.lightFetches++;
+    const float4 lcN = S.lightConst[(size_t)lightIndex * 4], lcNN = S.lightConst[(size_t)lightIndex * 4 + 3];
     v3 lsNormal, lsDirection;
     float lsDistance, lsPdf;
     if (light.type == PT_LIGHT_TYPE_SPOT) {
-        lsNormal = normalize3(light.u);
+        lsNormal = mk3(lcN.x, lcN.y, lcN.z);                     // normalize(light.u)
         lsDirection = -normalize3(scatterPos - light.position);
         lsDistance = length3(light.position - scatterPos);
         lsPdf = 0.0f;
@@ -1170,7 +1200,7 @@ PT_DEV void nee_prepare_light(const DScene& S, v3 rayDir, const SurfHit& hit, co
         lsDistance = length3(lsDirection);
         float distSq = lsDistance * lsDistance;
         lsDirection = lsDirection / lsDistance;
-        lsNormal = normalize3(cross3(light.u, light.v));
+        lsNormal = mk3(lcN.x, lcN.y, lcN.z);                     // normalize(cross(light.u, light.v))
         lsPdf = distSq / (light.area * pt_abs(dot3(lsNormal, lsDirection)));
     } else if (light.type == PT_LIGHT_TYPE_POINT) {
         lsNormal = normalize3(scatterPos - light.position);
@@ -1188,12 +1218,13 @@ PT_DEV void nee_prepare_light(const DScene& S, v3 rayDir, const SurfHit& hit, co
         float atten = pt_saturate(1.0f / (1.0f + 25.0f * r * r) * pt_saturate((1.0f - r) * 5.0f));
         falloff *= atten;
     }
+    const v3 lsNormalN = mk3(lcNN.x, lcNN.y, lcNN.z);            // normalize(lsNormal) of a rectangle / spot light
     if (light.type == PT_LIGHT_TYPE_RECTANGLE) {
-        float cosTheta = dot3(normalize3(-lsDirection), normalize3(lsNormal));
+        float cosTheta = dot3(normalize3(-lsDirection), lsNormalN);
         falloff = cosTheta < 0.0f ? 0.0f : falloff;
     }
     if (light.type == PT_LIGHT_TYPE_SPOT) {
-        float cosTheta = dot3(normalize3(-lsDirection), normalize3(lsNormal));
+        float cosTheta = dot3(normalize3(-lsDirection), lsNormalN);
         if (cosTheta < light.v.x) falloff = 0.0f;
         else if (cosTheta > light.v.x && cosTheta < light.v.y) falloff *= (cosTheta - light.v.x) / (light.v.y - light.v.x);
     }

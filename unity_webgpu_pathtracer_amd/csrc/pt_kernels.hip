@@ -92,7 +92,25 @@ __global__ __launch_bounds__(256, PT_MK_MIN_WAVES) void pt_megakernel(DScene S, 
     }
 }
 
+// one lane per light: the constants of derive_light_rows (pt_device.h), evaluated once per scene
+__global__ void pt_derive_lights(DScene S, float4* lightConst)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= S.lightCount) return;
+    float4 rows[4];
+    derive_light_rows(load_light(S, i), rows);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lightConst[(size_t)i * 4 + k] = rows[k];
+}
+
 } // namespace
+
+hipError_t pt_launch_derive_lights(const DScene& S, float4* lightConst, hipStream_t stream)
+{
+    if (S.lightCount <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pt_derive_lights, dim3((S.lightCount + 63) / 64), dim3(64), 0, stream, S, lightConst);
+    return hipGetLastError();
+}
 
 hipError_t pt_launch_megakernel(const DScene& S, const PTFrameParams& P, const float4* accumulated, float4* output,
                                 const PTTileMap& tm, unsigned long long* gstats, bool fullStats, hipStream_t stream)

@@ -48,6 +48,9 @@ inline PTTileMap pt_make_tile_map(const PTFrameParams& p, int rank, int world)
 hipError_t pt_launch_pack_tiles(const PTTileMap& tm, uint32_t frameWidth, const float4* frame, float4* packed, hipStream_t stream);
 hipError_t pt_launch_unpack_tiles(const PTTileMap& tm, uint32_t frameWidth, const float4* packed, float4* frame, hipStream_t stream);
 
+// per-light constants (pt_device.h derive_light_rows): S.lights / S.lightCount must be set; lightConst holds 64 bytes per light
+hipError_t pt_launch_derive_lights(const DScene& S, float4* lightConst, hipStream_t stream);
+
 hipError_t pt_launch_megakernel(const DScene& S, const PTFrameParams& P, const float4* accumulated, float4* output,
                                 const PTTileMap& tm, unsigned long long* gstats, bool fullStats, hipStream_t stream);
 
