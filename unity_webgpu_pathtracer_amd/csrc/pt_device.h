@@ -261,10 +261,6 @@ PT_DEV void intersect_triangle(const float4* __restrict__ tris, uint32_t triAddr
     // (left to itself hipcc sinks the v0 load under the determinant test: two dependent round trips)
     float4 t0 = tris[triAddr + 0], t1 = tris[triAddr + 1], t2 = tris[triAddr + 2];
     asm volatile("" : "+v"(t0.x), "+v"(t1.x), "+v"(t2.x), "+v"(t2.w));
-#ifdef PT_EXP_TRI_EXTRA_VALU
-#pragma unroll
-    for (int i = 0; i < PT_EXP_TRI_EXTRA_VALU; ++i) asm volatile("v_mov_b32 %0, %0" : "+v"(t0.x));       // EXPERIMENT: sensitivity to triangle-block VALU
-#endif
     intersect_triangle_rows<false>(t0, t1, t2, 0u, o, d, hit);
 }
 
@@ -307,17 +303,6 @@ PT_DEV void cwbvh_visit_node(const uint4* __restrict__ nodes, uint32_t nodeOffse
     const uint32_t childNodeIndex = cwbvh_pick_child<STATS>(ng, octinv4, sp, overflow, st, cn);
     const uint4* np = nodes + (size_t)(nodeOffset + childNodeIndex) * 5;
     uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-#ifdef PT_EXP_EXTRA_LOAD
-    {   // EXPERIMENT: TA sensitivity -- one more 16-byte row request per node visit (result unused but waited for)
-        uint4 x;
-        asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(x) : "v"(np + 2) : "memory");
-        asm volatile("" :: "v"(x.x));
-    }
-#endif
-#ifdef PT_EXP_EXTRA_VALU
-#pragma unroll
-    for (int i = 0; i < PT_EXP_EXTRA_VALU; ++i) asm volatile("v_mov_b32 %0, %0" : "+v"(n0.x));   // EXPERIMENT: VALU-issue sensitivity
-#endif
     cwbvh_apply_node<STATS>(o, invDir, octinv4, tmax, n0, n1, n2, n3, n4, ng, tg, cn);
 }
 
