@@ -54,14 +54,19 @@ def per_pass(rows, value_of):
     return [total / n_pass] * n_pass, {k: v / n_pass for k, v in per_kernel.items()}
 
 
+def newest(pattern):
+    """gpurun merges every call's files into gpurun_out/: several runs of one pass may lie side by side -- take the latest."""
+    return sorted(glob.glob(pattern), key=os.path.getmtime, reverse=True)
+
+
 def main():
     tag = sys.argv[1]
     workload = sys.argv[2] if len(sys.argv) > 2 else "sponza"
     base = os.path.join(ROOT, "gpurun_out")
-    stats = glob.glob(os.path.join(base, f"{tag}_trace", "*", "*_kernel_stats.csv"))
+    stats = newest(os.path.join(base, f"{tag}_trace", "*", "*_kernel_stats.csv"))
     if stats:
         shutil.copy(stats[0], os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))
-    trace = glob.glob(os.path.join(base, f"{tag}_trace", "*", "*_kernel_trace.csv"))
+    trace = newest(os.path.join(base, f"{tag}_trace", "*", "*_kernel_trace.csv"))
     out = {"tag": tag, "workload": workload}
     if trace:
         rows = [r for r in csv.DictReader(open(trace[0])) if "pt_" in r["Kernel_Name"]]
@@ -80,13 +85,13 @@ def main():
         out["span_ms_per_pass"] = (t1 - t0) / 1e6 / max(1, n_pass)
     pmc = {}
     for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-        f = glob.glob(os.path.join(base, f"{tag}_{kind}", "*", "*_counter_collection.csv"))
+        f = newest(os.path.join(base, f"{tag}_{kind}", "*", "*_counter_collection.csv"))
         if not f:
             continue
         rows = [r for r in csv.DictReader(open(f[0])) if "pt_" in r["Kernel_Name"] and r["Counter_Name"] == counter]
         passes, per_kernel = per_pass(rows, lambda r: float(r["Counter_Value"]))
         pmc[counter] = {"KiB_per_pass": sum(passes) / max(1, len(passes)), "passes": len(passes), "KiB_per_pass_by_kernel": per_kernel}
-    f = glob.glob(os.path.join(base, f"{tag}_valu", "*", "*_counter_collection.csv"))
+    f = newest(os.path.join(base, f"{tag}_valu", "*", "*_counter_collection.csv"))
     if f:
         allrows = [r for r in csv.DictReader(open(f[0])) if "pt_" in r["Kernel_Name"]]
         for counter in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"):
@@ -104,7 +109,7 @@ def main():
                        "source": "rocprofv3 --pmc SQ_INSTS_VALU (profiles/collect.sh %s), summed over the kernels of a pass; profiles/%s_pmc.json" % (tag, tag)},
                       open(os.path.join(ROOT, "profiles", "valu_insts.json"), "w"), indent=1)
     # where the wave-cycles go, per kernel: ACTIVE (issuing) / WAIT_INST_ANY (ready, waiting to issue) / WAIT_ANY (parked on s_waitcnt)
-    f = glob.glob(os.path.join(base, f"{tag}_wait", "*", "*_counter_collection.csv"))
+    f = newest(os.path.join(base, f"{tag}_wait", "*", "*_counter_collection.csv"))
     if f:
         agg = {}
         for r in csv.DictReader(open(f[0])):
@@ -124,7 +129,7 @@ def main():
     # vector-memory path, L2 and dispatcher counters, summed per kernel over the profiled passes (one rocprofv3 run per block)
     mem = {}
     for name in ("ta", "td", "tcp", "tcc", "grbm", "spi"):
-        f = glob.glob(os.path.join(base, f"{tag}_{name}", "*", "*_counter_collection.csv"))
+        f = newest(os.path.join(base, f"{tag}_{name}", "*", "*_counter_collection.csv"))
         if not f:
             continue
         for r in csv.DictReader(open(f[0])):
