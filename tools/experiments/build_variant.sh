@@ -8,7 +8,7 @@ DEFS="$*"
 cd "$(dirname "$0")/../../unity_webgpu_pathtracer_amd/csrc"
 make -s >/dev/null
 mkdir -p ../../tools/experiments/variants/_obj_$NAME
-FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fvisibility=hidden -I../../include -Wno-unused-function -Wno-unused-value $EXTRA_FLAGS"
+FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fvisibility=hidden -I../../include -Wno-unused-function -Wno-unused-value -mllvm -amdgpu-sched-strategy=max-memory-clause $EXTRA_FLAGS"
 for f in pt_wavefront pt_kernels pt_api; do
   hipcc --offload-arch=gfx950 $FLAGS $DEFS -c $f.hip -o ../../tools/experiments/variants/_obj_$NAME/$f.o &
 done
