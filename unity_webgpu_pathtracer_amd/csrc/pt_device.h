@@ -197,7 +197,7 @@ PT_DEV uint32_t cwbvh_node_hitmask(v3 origin, v3 invDir, uint32_t octinv4, float
         uint32_t loy = ny ? qhiy : qloy, hiy = ny ? qloy : qhiy;
         uint32_t loz = nz ? qhiz : qloz, hiz = nz ? qloz : qhiz;
         uint32_t isInner = (meta & (meta << 1)) & 0x10101010u;
-        uint32_t innerMask = (isInner >> 4) * 0xffu;
+        uint32_t innerMask = ((isInner >> 4) << 8) - (isInner >> 4);              // == (isInner >> 4) * 0xff without the quarter-rate v_mul_lo_u32
         uint32_t bitIndex = (meta ^ (octinv4 & innerMask)) & 0x1F1F1F1Fu;
         uint32_t childBits = (meta >> 5) & 0x07070707u;
 #pragma unroll
@@ -259,7 +259,8 @@ PT_DEV void intersect_triangle(const float4* __restrict__ tris, uint32_t triAddr
 {
     // all 48 bytes are requested before the first use, so the whole test costs ONE memory round trip
     // (left to itself hipcc sinks the v0 load under the determinant test: two dependent round trips)
-    float4 t0 = tris[triAddr + 0], t1 = tris[triAddr + 1], t2 = tris[triAddr + 2];
+    const float4* tp = tris + triAddr;                    // one address, rows at immediate offsets 0 / 16 / 32
+    float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
     asm volatile("" : "+v"(t0.x), "+v"(t1.x), "+v"(t2.x), "+v"(t2.w));
     intersect_triangle_rows<false>(t0, t1, t2, 0u, o, d, hit);
 }
@@ -373,7 +374,8 @@ PT_DEV v4 mul44c(float4 c0, float4 c1, float4 c2, float4 c3, v4 v)   // Matrix4x
 
 PT_DEV bool intersect_triangle_inst(const float4* __restrict__ tris, uint32_t triAddr, uint32_t attrOffset, v3 o, v3 d, TraceHit& hit)
 {
-    float4 t0 = tris[triAddr + 0], t1 = tris[triAddr + 1], t2 = tris[triAddr + 2];
+    const float4* tp = tris + triAddr;                    // one address, rows at immediate offsets 0 / 16 / 32
+    float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
     asm volatile("" : "+v"(t0.x), "+v"(t1.x), "+v"(t2.x), "+v"(t2.w));
     return intersect_triangle_rows<true>(t0, t1, t2, attrOffset, o, d, hit);
 }
