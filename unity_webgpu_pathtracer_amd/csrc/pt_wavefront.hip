@@ -155,7 +155,8 @@ __global__ __launch_bounds__(256, 4) void pt_wf_trace(DScene S, PTWfBuffers B)
 // hostage, and the enumeration order -- hence every result -- is independent of timing.
 // ------------------------------------------------------------------------------------------
 #ifndef PT_WF_RANGE
-#define PT_WF_RANGE 64u         // slots per wave (power of two); small ranges balance load across CUs (measured 64 > 128 > 256)
+#define PT_WF_RANGE 128u        // slots per wave (power of two): two 8x8 tiles x 3 kinds = 384 candidate rays.  64 / 128 / 256: 4,590 / 4,700 / 4,690
+                                // Mrays/s (before the compiler-flag changes of round 2 the order was 64 > 128 > 256)
 #endif
 static_assert(PT_WF_RANGE >= 64u && (PT_WF_RANGE & (PT_WF_RANGE - 1u)) == 0u,
               "one counter row per trace wave: pt_api.hip sizes statRows for 4 x numSlots/64 rows; the main trace launch uses rows numSlots/64 + wave, the tail launch rows 2 x numSlots/64 + wave");
