@@ -466,7 +466,7 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(
 #endif
 
 #ifndef PT_WF_TLAS_MIN_WAVES
-#define PT_WF_TLAS_MIN_WAVES 5
+#define PT_WF_TLAS_MIN_WAVES 6      // 80 VGPRs, no scratch (without the SLP vectorizer); 5 waves: -3 %
 #endif
 template <bool STATS>
 __global__ __launch_bounds__(64, PT_WF_TLAS_MIN_WAVES) void pt_wf_trace_refill_tlas(DScene S, PTWfBuffers B)
