@@ -155,8 +155,8 @@ __global__ __launch_bounds__(256, 4) void pt_wf_trace(DScene S, PTWfBuffers B)
 // hostage, and the enumeration order -- hence every result -- is independent of timing.
 // ------------------------------------------------------------------------------------------
 #ifndef PT_WF_RANGE
-#define PT_WF_RANGE 128u        // slots per wave (power of two): two 8x8 tiles x 3 kinds = 384 candidate rays.  64 / 128 / 256: 4,590 / 4,700 / 4,690
-                                // Mrays/s (before the compiler-flag changes of round 2 the order was 64 > 128 > 256)
+#define PT_WF_RANGE 128u        // largest slots-per-wave the launcher may pick (power of two): two 8x8 tiles x 3 kinds = 384 candidate rays.
+                                // Full 1080p frame, 64 / 128 / 256: 4,590 / 4,700 / 4,690 Mrays/s; small launches use 64 (pt_launch_wavefront)
 #endif
 static_assert(PT_WF_RANGE >= 64u && (PT_WF_RANGE & (PT_WF_RANGE - 1u)) == 0u,
               "one counter row per trace wave: pt_api.hip sizes statRows for 4 x numSlots/64 rows; the main trace launch uses rows numSlots/64 + wave, the tail launch rows 2 x numSlots/64 + wave");
@@ -246,7 +246,8 @@ PT_DEV void suspend_ray(const PTWfBuffers& B, uint32_t rec, uint32_t slot, uint3
     }
 }
 
-template <bool STATS, bool TAIL>
+// RANGE: slots per wave (64 or 128; pt_launch_wavefront picks by the size of the launch)
+template <bool STATS, bool TAIL, uint32_t RANGE>
 __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(DScene S, PTWfBuffers B)
 {
     __shared__ uint2 s_stack[PT_WF_LDS_STACK][64];
@@ -256,14 +257,14 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(
     __shared__ uint32_t s_gw;
     const uint32_t lane = threadIdx.x;
     const uint32_t gw = blockIdx.x;
-    const uint32_t numWaves = (B.numSlots + PT_WF_RANGE - 1u) / PT_WF_RANGE;
-    const uint32_t slotBase = gw * PT_WF_RANGE;
+    const uint32_t numWaves = (B.numSlots + RANGE - 1u) / RANGE;
+    const uint32_t slotBase = gw * RANGE;
     volatile uint32_t* xchg = s_xchg;
     if (lane == 0u) s_gw = gw;
 
     // candidates: the main launch scans the flag words of its slot range, kind-major; the tail launch walks the records that
     // its PT_WF_TAIL_GROUP source waves left behind (their indices, packed, in s_xchg)
-    uint32_t nItems = 3u * PT_WF_RANGE;
+    uint32_t nItems = 3u * RANGE;
     if (TAIL) {
         const uint32_t s0 = gw * PT_WF_TAIL_GROUP;
         uint32_t c = 0u;
@@ -303,8 +304,8 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(
             const uint32_t rankI = rank_below(idle);
             if (!TAIL) {
                 const uint32_t item = cursor + lane;
-                const uint32_t kind = item / PT_WF_RANGE;
-                const uint32_t slot = slotBase + (item & (PT_WF_RANGE - 1u));
+                const uint32_t kind = item / RANGE;
+                const uint32_t slot = slotBase + (item & (RANGE - 1u));
                 bool valid = item < nItems && slot < B.numSlots;
                 if (valid) valid = ray_exists(B.flags[slot], kind);
                 const unsigned long long V = __ballot(valid);
@@ -317,8 +318,8 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(
                 __builtin_amdgcn_wave_barrier();
                 if (!have && rankI < take) {
                     const uint32_t it = xchg[rankI];
-                    myKind = it / PT_WF_RANGE;
-                    mySlot = slotBase + (it & (PT_WF_RANGE - 1u));
+                    myKind = it / RANGE;
+                    mySlot = slotBase + (it & (RANGE - 1u));
                     v3 o, d;
                     fetch_ray(B, mySlot, myKind, o, d);
                     if (myKind == 0u) cn.closestRays++; else cn.shadowRays++;
@@ -1010,12 +1011,26 @@ hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const fl
             if (fullStats) hipLaunchKernelGGL(pt_wf_trace_persist<true>, dim3(waves), dim3(64), 0, stream, S, B);
             else hipLaunchKernelGGL(pt_wf_trace_persist<false>, dim3(waves), dim3(64), 0, stream, S, B);
         } else if (traceVariant == 2) {
-            if (fullStats) hipLaunchKernelGGL((pt_wf_trace_refill<true, false>), dim3(refillBlocks), dim3(64), 0, stream, S, B);
-            else hipLaunchKernelGGL((pt_wf_trace_refill<false, false>), dim3(refillBlocks), dim3(64), 0, stream, S, B);
+            // 128 slots per wave while that still gives half the wave slots of the device a wave (1080p: 16,320 waves for 8,192
+            // slots, +2.4 %; half a frame: 9.9 vs 10.2 ms; a quarter: equal); 64 for smaller launches (1/8 of a frame: 3.3 vs 3.7 ms)
+            const bool wide = PT_WF_RANGE >= 128u && (B.numSlots / 128u) >= B.residentWaves / 2u;
+            const uint32_t blocks = wide ? (B.numSlots + 127u) / 128u : (B.numSlots + 63u) / 64u;
+            if (wide) {
+                if (fullStats) hipLaunchKernelGGL((pt_wf_trace_refill<true, false, 128u>), dim3(blocks), dim3(64), 0, stream, S, B);
+                else hipLaunchKernelGGL((pt_wf_trace_refill<false, false, 128u>), dim3(blocks), dim3(64), 0, stream, S, B);
+            } else {
+                if (fullStats) hipLaunchKernelGGL((pt_wf_trace_refill<true, false, 64u>), dim3(blocks), dim3(64), 0, stream, S, B);
+                else hipLaunchKernelGGL((pt_wf_trace_refill<false, false, 64u>), dim3(blocks), dim3(64), 0, stream, S, B);
+            }
             if (PT_WF_SUSPEND > 0u) {
-                const uint32_t tailBlocks = (refillBlocks + PT_WF_TAIL_GROUP - 1u) / PT_WF_TAIL_GROUP;
-                if (fullStats) hipLaunchKernelGGL((pt_wf_trace_refill<true, true>), dim3(tailBlocks), dim3(64), 0, stream, S, B);
-                else hipLaunchKernelGGL((pt_wf_trace_refill<false, true>), dim3(tailBlocks), dim3(64), 0, stream, S, B);
+                const uint32_t tailBlocks = (blocks + PT_WF_TAIL_GROUP - 1u) / PT_WF_TAIL_GROUP;
+                if (wide) {
+                    if (fullStats) hipLaunchKernelGGL((pt_wf_trace_refill<true, true, 128u>), dim3(tailBlocks), dim3(64), 0, stream, S, B);
+                    else hipLaunchKernelGGL((pt_wf_trace_refill<false, true, 128u>), dim3(tailBlocks), dim3(64), 0, stream, S, B);
+                } else {
+                    if (fullStats) hipLaunchKernelGGL((pt_wf_trace_refill<true, true, 64u>), dim3(tailBlocks), dim3(64), 0, stream, S, B);
+                    else hipLaunchKernelGGL((pt_wf_trace_refill<false, true, 64u>), dim3(tailBlocks), dim3(64), 0, stream, S, B);
+                }
                 launches++;
             }
         } else if (tlas && tlasRefill) {
