@@ -842,10 +842,11 @@ PT_DEV bool shade_slot(const DScene& S, const PTFrameParams& P, const PTTileMap&
     return r.state != PS_DONE;
 }
 
-// one lane per slot.  (Compacting the live slots into full waves was tried and is slower: the kernel is a chain of
-// dependent fetches at 3 waves/SIMD, so fewer, longer waves lose more than the idle lanes cost.)
+// one lane per slot, in screen order.  (Walking a compacted or class-sorted list of live slots instead was built twice and is
+// slower -- round 2: shade VALU -41 %, throughput -20 % -- because path state is then read and written through gathers;
+// DESIGN.md 5.1.)
 #ifndef PT_WF_SHADE_BLOCK
-#define PT_WF_SHADE_BLOCK 64u          // one wave per workgroup: a finished wave frees its 168 VGPRs at once (256 -> 64: +4 %)
+#define PT_WF_SHADE_BLOCK 64u          // one wave per workgroup: a finished wave frees its 128 VGPRs at once (256 -> 64: +4 %)
 #endif
 template <bool STATS>
 __global__ __launch_bounds__(PT_WF_SHADE_BLOCK, PT_WF_SHADE_MIN_WAVES) void pt_wf_shade(DScene S, PTFrameParams P, PTTileMap tm, PTWfBuffers B,
