@@ -170,6 +170,9 @@ static_assert(PT_WF_RANGE >= 64u && (PT_WF_RANGE & (PT_WF_RANGE - 1u)) == 0u,
 #define PT_WF_TRI_PARK 4u       // > 0: two-phase wave iteration (ray_tri_one / ray_node_one); lanes with triangles pending wait until
                                 // that many lanes do.  0: ray_step's nested loops.  2 ... 12 measure the same (+6 %), 16: +3 %, 24: -2 %
 #endif
+#ifndef PT_WF_HIT_REGS
+#define PT_WF_HIT_REGS 1        // main refill launch (with PT_WF_TRI_PARK): the hit's (u, v, triIndex) stay in registers until the ray ends
+#endif
 #if PT_WF_FLAT == 2
 #define PT_WF_STEP ray_unistep
 #else
@@ -394,12 +397,16 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(
                 if ((nT >= PT_WF_TRI_PARK || nN == 0u) && wantTri) {
                     const float tBefore = rs.hit.t;
                     fin = ray_tri_one<STATS>(S, rs, cn);
-                    // the hit record goes to memory when a test improved it: (u, v, triIndex) need no registers across iterations
-                    if (myKind == 0u && rs.hit.t < tBefore) f4_array(B, PT_F4_HIT)[mySlot] = make_float4(rs.hit.t, rs.hit.u, rs.hit.v, pt_asfloat(rs.hit.triIndex));
+                    // TAIL: the hit record goes to memory when a test improved it (a resumed ray has only t in registers).
+                    // main launch (PT_WF_HIT_REGS): (u, v, triIndex) stay in registers and are written once, when the ray finishes or is suspended
+                    if ((TAIL || !PT_WF_HIT_REGS) && myKind == 0u && rs.hit.t < tBefore) f4_array(B, PT_F4_HIT)[mySlot] = make_float4(rs.hit.t, rs.hit.u, rs.hit.v, pt_asfloat(rs.hit.triIndex));
                 }
                 if (have && !fin && rs.tg.y == 0u) fin = ray_node_one<STATS>(S, rs, st, cn);
                 if (fin) {
-                    if (myKind == 0u) { if (!(rs.hit.t < PT_FAR_PLANE)) store_miss(B, mySlot); }
+                    if (myKind == 0u) {
+                        if (!(rs.hit.t < PT_FAR_PLANE)) store_miss(B, mySlot);
+                        else if (!TAIL && PT_WF_HIT_REGS) f4_array(B, PT_F4_HIT)[mySlot] = make_float4(rs.hit.t, rs.hit.u, rs.hit.v, pt_asfloat(rs.hit.triIndex));
+                    }
                     else store_occlusion(B, myKind, mySlot, rs.hit.t < PT_FAR_PLANE);
                     have = false;
                 }
@@ -432,16 +439,21 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(
 #else
                         const bool fin = PT_WF_STEP<STATS>(S, rs, st, cn);
 #endif
-                        if (myKind == 0u && rs.hit.t < tBefore) f4_array(B, PT_F4_HIT)[mySlot] = make_float4(rs.hit.t, rs.hit.u, rs.hit.v, pt_asfloat(rs.hit.triIndex));
+                        if ((TAIL || !PT_WF_HIT_REGS || PT_WF_TRI_PARK == 0u) && myKind == 0u && rs.hit.t < tBefore) f4_array(B, PT_F4_HIT)[mySlot] = make_float4(rs.hit.t, rs.hit.u, rs.hit.v, pt_asfloat(rs.hit.triIndex));
                         if (fin) {
-                            if (myKind == 0u) { if (!(rs.hit.t < PT_FAR_PLANE)) store_miss(B, mySlot); }
-                            else store_occlusion(B, myKind, mySlot, rs.hit.t < PT_FAR_PLANE);
+                            if (myKind == 0u) {
+                                if (!(rs.hit.t < PT_FAR_PLANE)) store_miss(B, mySlot);
+                                else if (!TAIL && PT_WF_HIT_REGS && PT_WF_TRI_PARK > 0u) f4_array(B, PT_F4_HIT)[mySlot] = make_float4(rs.hit.t, rs.hit.u, rs.hit.v, pt_asfloat(rs.hit.triIndex));
+                            } else store_occlusion(B, myKind, mySlot, rs.hit.t < PT_FAR_PLANE);
                             have = false;
                         }
                     }
                 }
             }
             const unsigned long long act = __ballot(have);
+            // a suspended bounce ray leaves its best hit so far in the hit array (the tail launch writes there only when it improves it)
+            if (PT_WF_HIT_REGS && PT_WF_TRI_PARK > 0u && have && myKind == 0u && rs.hit.t < PT_FAR_PLANE)
+                f4_array(B, PT_F4_HIT)[mySlot] = make_float4(rs.hit.t, rs.hit.u, rs.hit.v, pt_asfloat(rs.hit.triIndex));
             if (have) suspend_ray(B, *PT_LDS_WORD(s_gw) * PT_WF_SUSPEND + rank_below(act), mySlot, myKind, rs, st);
             have = false;
             nSuspended = (uint32_t)__popcll(act);
