@@ -296,8 +296,8 @@ def main():
                          "max_stack_depth": main_res["max_stack_depth"],
                          "valu_issue": valu,
                          "note": "rank-0 kernels; achieved = algorithmic bytes of a pass / its device time (HIP events on the context stream, passes overlap); "
-                                 "the scene is Infinity-Cache resident, so HBM is the nominal roof only: the pass is bound by divergent-gather throughput of the "
-                                 "vector memory path and by VALU issue under ~50 % lane utilisation (DESIGN.md 5.4)"},
+                                 "the scene is Infinity-Cache resident, so HBM is the nominal roof only: the pass is bound by VALU issue at 40-55 % lane "
+                                 "utilisation (valu_issue.frac), with the texture-data path ~70 % busy (DESIGN.md 5.4)"},
         }
     if not args.no_extra and not distributed:
         extra = {}
