@@ -34,7 +34,7 @@ import numpy as np
 # consecutive passes overlap on PT_WF_SETS streams; the HIP runtime maps streams onto this many hardware queues (default 4)
 # and streams that share a queue serialise.  Must be set before the first HIP call (the plugin sets the same default when
 # it is loaded first; here torch initialises HIP before the plugin is loaded).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:

@@ -16,9 +16,9 @@ def run(k0, n):
         t0 = time.perf_counter(); pt.render_pass(p); pt.flip(); t.append(time.perf_counter() - t0)
     pt.synchronize()
     return t
-run(0, 6)
+run(0, 16)                    # more passes than state sets: every set allocated and touched before the timed region
 pt.reset_stats()
-t0=time.perf_counter(); t = run(6, K); wall=(time.perf_counter()-t0)*1e3/K
+t0=time.perf_counter(); t = run(16, K); wall=(time.perf_counter()-t0)*1e3/K
 rays = pt.stats().rays / K
 print(f"{os.environ.get('PT_PLUGIN','default').split('/')[-1]} q={os.environ.get('GPU_MAX_HW_QUEUES')} world {world} iters {iters}: {wall:.2f} ms/pass -> {rays/wall/1e3*world:.0f} Mrays/s aggregate; host launch per pass: mean {sum(t)/len(t)*1e3:.2f} ms", flush=True)
 pt.close()

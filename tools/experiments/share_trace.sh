@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (GPU box): bash tools/experiments/share_trace.sh WORLD -- kernel trace of rank 0's share of a WORLD-way sharded frame
-export TMPDIR=/tmp GPU_MAX_HW_QUEUES=8
+export TMPDIR=/tmp GPU_MAX_HW_QUEUES=16
 timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/share_kt -- python3 tools/experiments/share8.py $1 > gpurun_out/share_kt.log 2>&1
 tail -2 gpurun_out/share_kt.log | head -1
 python3 tools/experiments/overlap.py gpurun_out/share_kt

@@ -19,10 +19,10 @@ namespace {
 
 // Consecutive passes run on PT_WF_SETS streams so that one pass's launch tails are filled by its neighbours' kernels.  The
 // HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, one of them the context stream's):
-// streams that share a queue serialise.  Ask for 8 unless the host has already chosen; this runs when the library is loaded,
+// streams that share a queue serialise.  Ask for 16 (12 set streams + the context stream) unless the host has already chosen; this runs when the library is loaded,
 // i.e. before the first HIP call of a host that loads the plugin first (a host that has initialised HIP already keeps its
 // own setting -- bench.py therefore sets the variable itself before importing torch).
-__attribute__((constructor)) void pt_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+__attribute__((constructor)) void pt_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 thread_local std::string g_lastError;
 
@@ -361,7 +361,10 @@ int render_to(PTContext* c, const PTFrameParams* hostParams, float4* dOut, const
         const uint64_t maxIt = (uint64_t)spp * (bounces + 2u) + 4u;
         PTContext::WfSet& set = c->sets[c->nextSet];
         c->nextSet = (c->nextSet + 1u) % PT_WF_SETS;
-        if ((rc = ensure_wavefront(c, set, pt_num_slots(tm), (uint32_t)(maxIt > 65536u ? 65536u : maxIt)))) return rc;
+        // every set is carved on the FIRST pass of a frame size (a no-op afterwards): a caller that times passes after a short
+        // warm-up must not find the allocation of sets it has not reached yet inside its timed region
+        for (auto& other : c->sets)
+            if ((rc = ensure_wavefront(c, other, pt_num_slots(tm), (uint32_t)(maxIt > 65536u ? 65536u : maxIt)))) return rc;
         // the launch chain runs on the set's own stream; only its resolve (which reads `accumulated` and writes `output`)
         // is ordered after what the caller has enqueued on the context stream so far, the previous pass included
         HIP_TRY(hipEventRecord(set.callEv, c->stream));
