@@ -173,6 +173,10 @@ static_assert(PT_WF_RANGE >= 64u && (PT_WF_RANGE & (PT_WF_RANGE - 1u)) == 0u,
 #ifndef PT_WF_HIT_REGS
 #define PT_WF_HIT_REGS 1        // main refill launch (with PT_WF_TRI_PARK): the hit's (u, v, triIndex) stay in registers until the ray ends
 #endif
+#ifndef PT_WF_WIDE_DIV
+#define PT_WF_WIDE_DIV 4u       // 128-slot ranges while the launch still has residentWaves / PT_WF_WIDE_DIV waves (with 12 sets in flight:
+                                // 1/4 of a 1080p frame 5.09 vs 5.21 ms, 1/8 equal either way)
+#endif
 #if PT_WF_FLAT == 2
 #define PT_WF_STEP ray_unistep
 #else
@@ -1024,9 +1028,9 @@ hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const fl
             if (fullStats) hipLaunchKernelGGL(pt_wf_trace_persist<true>, dim3(waves), dim3(64), 0, stream, S, B);
             else hipLaunchKernelGGL(pt_wf_trace_persist<false>, dim3(waves), dim3(64), 0, stream, S, B);
         } else if (traceVariant == 2) {
-            // 128 slots per wave while that still gives half the wave slots of the device a wave (1080p: 16,320 waves for 8,192
-            // slots, +2.4 %; half a frame: 9.9 vs 10.2 ms; a quarter: equal); 64 for smaller launches (1/8 of a frame: 3.3 vs 3.7 ms)
-            const bool wide = PT_WF_RANGE >= 128u && (B.numSlots / 128u) >= B.residentWaves / 2u;
+            // 128 slots per wave while that still gives a quarter of the wave slots of the device a wave (1080p: 16,320 waves for
+            // 8,192 slots, +2.4 %; half and quarter frames: +2 %); 64 for smaller launches
+            const bool wide = PT_WF_RANGE >= 128u && (B.numSlots / 128u) >= B.residentWaves / PT_WF_WIDE_DIV;
             const uint32_t blocks = wide ? (B.numSlots + 127u) / 128u : (B.numSlots + 63u) / 64u;
             if (wide) {
                 if (fullStats) hipLaunchKernelGGL((pt_wf_trace_refill<true, false, 128u>), dim3(blocks), dim3(64), 0, stream, S, B);
