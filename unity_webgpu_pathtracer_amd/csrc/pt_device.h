@@ -810,6 +810,13 @@ PT_DEV float power_heuristic(float a, float b) { float t = a * a; return t / (b 
 // ------------------------------------------------------------------------------------------
 struct Lobes { float dielectricWt, metalWt, glassWt, diffPr, dielectricPr, metalPr, glassPr, clearCtPr; };
 
+// What the three BSDF evaluations of one shading step (environment NEE, light NEE, the sampled direction) derive from the
+// MATERIAL alone -- util/brdf.hlsl TintColors -- and the frame of the face-forward normal that two of them share.  The
+// shader recomputes both inside every call (brdf.hlsl:118-131, :229, :246); evaluated once per step with the same
+// expressions the values are the same bits (~60 instructions per tint, ~30 per frame, 3 divisions each).  Affordable
+// since the shade kernel no longer holds its load addresses in registers (pt_wavefront.hip shade_slot): 10 more VGPRs.
+struct BsdfShared { float F0; v3 Csheen, Cspec0; };
+
 PT_DEV void tint_colors(const Material& mat, float eta, float& F0, v3& Csheen, v3& Cspec0)
 {
     float lum = luminance3(mat.baseColor);
@@ -903,7 +910,7 @@ PT_DEV v3 eval_clearcoat(const Material& mat, v3 V, v3 L, v3 H, float& pdf)
 }
 
 // util/brdf.hlsl:114-225.  V and L are world-space; onb = GetONB(N).
-PT_DEV v3 eval_brdf_onb(const Material& mat, v3 V, v3 L, const Onb& onb, float& pdf)
+PT_DEV v3 eval_brdf_onb(const Material& mat, v3 V, v3 L, const Onb& onb, float& pdf, const BsdfShared& sh)
 {
     pdf = 0.0f;
     v3 f = mk3(0.0f);
@@ -914,9 +921,8 @@ PT_DEV v3 eval_brdf_onb(const Material& mat, v3 V, v3 L, const Onb& onb, float& 
     else H = normalize3(L + V * mat.eta);
     if (H.z < 0.0f) H = -H;
 
-    v3 Csheen, Cspec0;
-    float F0;
-    tint_colors(mat, mat.eta, F0, Csheen, Cspec0);
+    const v3 Csheen = sh.Csheen, Cspec0 = sh.Cspec0;     // tint_colors(mat, mat.eta), evaluated once per shading step
+    const float F0 = sh.F0;
     Lobes w = lobe_weights(mat, Cspec0, V.z);
 
     bool refl = L.z * V.z > 0.0f;
@@ -961,23 +967,20 @@ PT_DEV v3 eval_brdf_onb(const Material& mat, v3 V, v3 L, const Onb& onb, float& 
     return f * pt_abs(L.z);
 }
 
-PT_DEV v3 eval_brdf(const Material& mat, v3 V, v3 N, v3 L, float& pdf)                  // util/brdf.hlsl:227-238
+PT_DEV v3 eval_brdf(const Material& mat, v3 V, v3 N, v3 L, float& pdf, const BsdfShared& sh)     // util/brdf.hlsl:227-238
 {
     Onb onb = make_onb(N);
-    return eval_brdf_onb(mat, V, L, onb, pdf);
+    return eval_brdf_onb(mat, V, L, onb, pdf, sh);
 }
 
-PT_DEV v3 sample_brdf(const Material& mat, v3 V, v3 N, v3& L, float& pdf, uint32_t& rng) // util/brdf.hlsl:240-340
+// onb = make_onb(N) of the caller (shared with the environment NEE evaluation, which uses the same normal)
+PT_DEV v3 sample_brdf(const Material& mat, v3 V, const Onb& onb, v3& L, float& pdf, uint32_t& rng, const BsdfShared& sh) // util/brdf.hlsl:240-340
 {
     pdf = 0.0f;
     float r1 = rnd(rng);
     float r2 = rnd(rng);
-    Onb onb = make_onb(N);
     V = onb_to_local(onb, V);
-    v3 Csheen, Cspec0;
-    float F0;
-    tint_colors(mat, mat.eta, F0, Csheen, Cspec0);
-    Lobes w = lobe_weights(mat, Cspec0, V.z);
+    Lobes w = lobe_weights(mat, sh.Cspec0, V.z);
     float cdf0 = w.diffPr;
     float cdf1 = cdf0 + w.dielectricPr;
     float cdf2 = cdf1 + w.metalPr;
@@ -1003,7 +1006,7 @@ PT_DEV v3 sample_brdf(const Material& mat, v3 V, v3 N, v3& L, float& pdf, uint32
     }
     L = onb_to_world(onb, L);
     V = onb_to_world(onb, V);
-    return eval_brdf_onb(mat, V, L, onb, pdf);
+    return eval_brdf_onb(mat, V, L, onb, pdf, sh);
 }
 
 // util/random.hlsl:34-41
@@ -1130,7 +1133,7 @@ PT_DEV v3 nee_scatter_pos(const SurfHit& hit) { return hit.position + hit.normal
 
 // environment half of DirectLight (:123-160)
 PT_DEV void nee_prepare_environment(const DScene& S, const PTFrameParams& P, v3 rayDir, const SurfHit& hit, const Material& mat,
-                                    uint32_t& rng, NeeRay& out)
+                                    uint32_t& rng, NeeRay& out, const BsdfShared& sh, const Onb& ffOnb)
 {
     out.valid = 0u;
     out.contribution = mk3(0.0f);
@@ -1149,7 +1152,7 @@ PT_DEV void nee_prepare_environment(const DScene& S, const PTFrameParams& P, v3 
     out.dir = lightDir;
     out.valid = 1u;
     float spdf = 0.0f;
-    v3 sf = eval_brdf(mat, -rayDir, hit.ffnormal, lightDir, spdf);
+    v3 sf = eval_brdf_onb(mat, -rayDir, lightDir, ffOnb, spdf, sh);          // ffOnb = make_onb(hit.ffnormal)
     if (spdf > 0.0f) {
         float misWeight = power_heuristic(lightPdf, spdf);
         if (misWeight > 0.0f) {
@@ -1162,7 +1165,7 @@ PT_DEV void nee_prepare_environment(const DScene& S, const PTFrameParams& P, v3 
 // analytic-light half of DirectLight (:162-170) + SampleOneLight (:47-58) + EvalLight (:60-114)
 template <bool STATS>
 PT_DEV void nee_prepare_light(const DScene& S, v3 rayDir, const SurfHit& hit, const Material& mat, v3 scatterPos,
-                              uint32_t& rng, NeeRay& out, Counters& cn)
+                              uint32_t& rng, NeeRay& out, Counters& cn, const BsdfShared& sh)
 {
     out.valid = 0u;
     out.contribution = mk3(0.0f);
@@ -1219,7 +1222,7 @@ PT_DEV void nee_prepare_light(const DScene& S, v3 rayDir, const SurfHit& hit, co
     out.dir = lsDirection;
     out.valid = 1u;
     float pdf = 0.0f;
-    v3 f = eval_brdf(mat, -rayDir, hit.normal, lsDirection, pdf);
+    v3 f = eval_brdf(mat, -rayDir, hit.normal, lsDirection, pdf, sh);
     float lightPdf = 1.0f;
     if (lsPdf > 0.0f) lightPdf = lsPdf;
     out.contribution = Li * f / lightPdf;
@@ -1343,10 +1346,14 @@ PT_DEV void path_init(const PTFrameParams& P, uint32_t pixelX, uint32_t pixelY, 
 // INLINE_RESOLVE: write the pixel (running mean with AccumulatedOutput) when its last sample ends, as the reference
 // kernel does.  Without it the pixel's sample sum stays in r.color and a separate resolve step applies the same formula
 // later (pt_wavefront.hip), which lets consecutive passes overlap.
-template <bool STATS, bool INLINE_RESOLVE = true>
+// NeeSink: called once the two NEE rays of a bounce are final (directions, contributions, origin, the throughput they apply
+// to), BEFORE the BSDF is sampled.  The wavefront shade kernel writes them to the slot arrays there, so that their 15
+// registers are free while sample_brdf runs (pt_wavefront.hip); the other schedules keep them in registers and pass nothing.
+struct NoNeeSink { PT_DEV void operator()(PathRegs&) const {} };
+template <bool STATS, bool INLINE_RESOLVE = true, class NeeSink = NoNeeSink>
 PT_DEV void path_step(const DScene& S, const PTFrameParams& P, PathRegs& r, const HitRecord& rec, bool occEnv, bool occLight,
                       uint32_t pixelX, uint32_t pixelY, uint32_t pixelIndex,
-                      const float4* __restrict__ accumulated, float4* __restrict__ output, Counters& cn)
+                      const float4* __restrict__ accumulated, float4* __restrict__ output, Counters& cn, NeeSink neeSink = NeeSink())
 {
     // ---- (1) radiance += DirectLight(...) * throughput      (util/pathtrace.hlsl:93, deferred until the shadow rays are in)
     if (r.hasPending) {
@@ -1407,12 +1414,16 @@ PT_DEV void path_step(const DScene& S, const PTFrameParams& P, PathRegs& r, cons
                     scatterL = r.rd;                             // rayDepth-- then ++: depth unchanged (util/pathtrace.hlsl:85-88)
                 } else {
                     r.neeOrigin = nee_scatter_pos(hit);
-                    nee_prepare_environment(S, P, r.rd, hit, material, r.rng, r.env);
-                    nee_prepare_light<STATS>(S, r.rd, hit, material, r.neeOrigin, r.rng, r.light, cn);
+                    BsdfShared sh;
+                    tint_colors(material, material.eta, sh.F0, sh.Csheen, sh.Cspec0);
+                    const Onb ffOnb = make_onb(hit.ffnormal);
+                    nee_prepare_environment(S, P, r.rd, hit, material, r.rng, r.env, sh, ffOnb);
+                    nee_prepare_light<STATS>(S, r.rd, hit, material, r.neeOrigin, r.rng, r.light, cn, sh);
                     r.pendThroughput = r.throughput;
                     r.hasPending = true;
+                    neeSink(r);
                     float pdf;
-                    v3 f = sample_brdf(material, -r.rd, hit.ffnormal, scatterL, pdf, r.rng);
+                    v3 f = sample_brdf(material, -r.rd, ffOnb, scatterL, pdf, r.rng, sh);
                     r.scatterPdf = pdf;
                     if (pt_isnan(f.x) || pt_isnan(f.y) || pt_isnan(f.z)) {
                         r.green = true;

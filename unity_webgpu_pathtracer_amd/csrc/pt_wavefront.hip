@@ -806,7 +806,8 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_persist
 #define PT_WF_SHADE_MIN_WAVES 3
 #endif
 
-// everything the shade step does for one slot (flags word f already read, state != DONE)
+// The path state of one slot as the flags word f describes it (state != DONE).  Used by the cleanup kernel; the shade kernel
+// requests the same words all at once (shade_slot).
 PT_DEV void load_path(const PTWfBuffers& B, uint32_t slot, uint32_t f, PathRegs& r)
 {
     r.state = fl_state(f);
@@ -832,29 +833,72 @@ PT_DEV void load_path(const PTWfBuffers& B, uint32_t slot, uint32_t f, PathRegs&
     }
 }
 
+// Everything the shade step does for one slot (flags word f already read, state != DONE).
+// Every word of the slot's state is requested up front in ONE batch, whether the flags say it is meaningful or not (the pending
+// NEE terms, the two occlusion bytes, the hit record): requested where they are used they formed a chain of four dependent
+// round trips (state -> pending terms -> occlusion bytes -> hit record, ~870 cycles each at the shade kernel's 4 waves/SIMD)
+// in front of the attribute / material / texture chain.  A value the flags do not cover is read and ignored.
 template <bool STATS>
 PT_DEV bool shade_slot(const DScene& S, const PTFrameParams& P, const PTTileMap& tm, const PTWfBuffers& B, uint32_t slot, uint32_t f,
                        Counters& cn)
 {
     uint32_t px, py;
     pt_slot_to_pixel(tm, slot, px, py);
+    uint32_t rng = B.rng[slot];
+    float4 qro = B.ro[slot], qrd = B.rd[slot], qrad = B.rad[slot], qthr = B.thr[slot], qcol = B.color[slot];
+    float4 qenvC = B.envC[slot], qlightC = B.lightC[slot], qpthr = B.pthr[slot], qhit = B.hit[slot];
+    uint32_t o0 = B.occl[slot], o1 = B.occl[(size_t)B.numSlots + slot];
+    float4 qhit2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (S.hasTlas) qhit2 = B.hit2[slot];
+    // pinned: left alone, the compiler sinks each load into the branch that uses it again
+    asm volatile("" : "+v"(rng), "+v"(qro.x), "+v"(qrd.x), "+v"(qrad.x), "+v"(qthr.x), "+v"(qcol.x), "+v"(qenvC.x), "+v"(qlightC.x), "+v"(qpthr.x),
+                      "+v"(qhit.x), "+v"(o0), "+v"(o1), "+v"(qhit2.x));
     PathRegs r;
-    load_path(B, slot, f, r);
-    bool occEnv = false, occLight = false;
-    if (r.hasPending) {
-        occEnv = B.occl[slot] != 0;
-        occLight = B.occl[(size_t)B.numSlots + slot] != 0;
-    }
+    r.state = fl_state(f);
+    r.hasPending = fl_pending(f);
+    r.env.valid = fl_env(f);
+    r.light.valid = fl_light(f);
+    r.green = (f >> 6) & 1u;
+    r.sampleIdx = (f >> 7) & 0xFFFu;
+    r.depth = f >> 19;
+    r.rng = rng;
+    r.ro = xyz(qro); r.scatterPdf = qro.w;
+    r.rd = xyz(qrd); r.maxRoughness = qrd.w;
+    r.radiance = xyz(qrad);
+    r.throughput = xyz(qthr);
+    r.color = xyz(qcol);
+    r.env.dir = mk3(0.0f); r.light.dir = mk3(0.0f); r.neeOrigin = mk3(0.0f);
+    r.env.contribution = r.hasPending ? xyz(qenvC) : mk3(0.0f);
+    r.light.contribution = r.hasPending ? xyz(qlightC) : mk3(0.0f);
+    r.pendThroughput = r.hasPending ? xyz(qpthr) : mk3(0.0f);
+    const bool occEnv = r.hasPending && o0 != 0u, occLight = r.hasPending && o1 != 0u;
     HitRecord ch;
     ch.h.t = PT_FAR_PLANE; ch.h.u = 0.0f; ch.h.v = 0.0f; ch.h.triIndex = 0u;
     ch.pos = mk3(0.0f); ch.inst = 0u;
     if (r.state == PS_TRACE) {
-        float4 h = B.hit[slot];
-        ch.h.t = h.x; ch.h.u = h.y; ch.h.v = h.z; ch.h.triIndex = pt_asuint(h.w);
-        if (S.hasTlas) { float4 h2 = B.hit2[slot]; ch.pos = xyz(h2); ch.inst = pt_asuint(h2.w); }
+        ch.h.t = qhit.x; ch.h.u = qhit.y; ch.h.v = qhit.z; ch.h.triIndex = pt_asuint(qhit.w);
+        if (S.hasTlas) { ch.pos = xyz(qhit2); ch.inst = pt_asuint(qhit2.w); }
     }
-    path_step<STATS, false>(S, P, r, ch, occEnv, occLight, px, py, py * P.OutputWidth + px, nullptr, nullptr, cn);
-    store_path(B, slot, r, r.hasPending);
+    // the NEE rays of the bounce go to their arrays as soon as they are final (NeeSink): 15 registers free while the BSDF is sampled
+    struct Sink {
+        const PTWfBuffers& B; uint32_t slot;
+        PT_DEV void operator()(PathRegs& q) const {
+            uint32_t s2 = slot;
+            asm volatile("" : "+v"(s2));
+            B.neeO[s2] = f4(q.neeOrigin, 0.0f);
+            B.envD[s2] = f4(q.env.dir, 0.0f);
+            B.lightD[s2] = f4(q.light.dir, 0.0f);
+            B.envC[s2] = f4(q.env.contribution, 0.0f);
+            B.lightC[s2] = f4(q.light.contribution, 0.0f);
+            B.pthr[s2] = f4(q.pendThroughput, 0.0f);
+        }
+    };
+    path_step<STATS, false, Sink>(S, P, r, ch, occEnv, occLight, px, py, py * P.OutputWidth + px, nullptr, nullptr, cn, Sink{B, slot});
+    // the store addresses are formed HERE from a slot the compiler cannot connect with the one the loads used: otherwise the
+    // thirteen 64-bit load addresses stay in registers across the whole step to be reused by these stores
+    uint32_t storeSlot = slot;
+    asm volatile("" : "+v"(storeSlot));
+    store_path(B, storeSlot, r, false);                             // the NEE arrays were written by the sink
     return r.state != PS_DONE;
 }
 
