@@ -1517,6 +1517,37 @@ int oracle_trace(const PTSceneDesc* scene, const OracleRay* rays, uint64_t n, fl
     return 0;
 }
 
+// The same restated traversal as oracle_trace, reporting the full closest-hit record per ray: out4[i] = {t, u, v, prim bits}
+// (prim = 0xFFFFFFFF, u = v = 0 on a miss).  Compared bit for bit with the reference's own CWBVH walker
+// (BVH8_CWBVH::Intersect, tiny_bvh.h:7006-7114, through oracle/ref_driver_cwbvh.cpp) by tests/test_oracle.py.
+int oracle_trace_uv(const PTSceneDesc* scene, const OracleRay* rays, uint64_t n, float* out4, uint64_t* outNodeVisits, uint64_t* outTriTests)
+{
+    if (!scene || !rays || !out4) return -1;
+    SceneView S = MakeView(scene);
+    PTFrameParams P;
+    memset(&P, 0, sizeof(P));
+    Ctx c;
+    c.S = &S; c.P = &P; memset(&c.st, 0, sizeof(PTStats)); c.shadowAnyHit = false; c.nanRayEarlyOut = false; c.opt = nullptr;
+    for (uint64_t i = 0; i < n; i++) {
+        Ray r = {V3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]),
+                 V3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2])};
+        RayHit hit;
+        memset(&hit, 0, sizeof(hit));
+        hit.distance = rays[i].tmax;
+        hit.triIndex = 0xFFFFFFFFu;
+        RayIntersectBvh(c, r, hit, true);                 // the shadow path = the traversal loop without the attribute fetch
+        const bool found = hit.distance < rays[i].tmax;
+        const uint32_t prim = found ? hit.triIndex : 0xFFFFFFFFu;
+        out4[i * 4 + 0] = hit.distance;
+        out4[i * 4 + 1] = found ? hit.barycentric.x : 0.0f;
+        out4[i * 4 + 2] = found ? hit.barycentric.y : 0.0f;
+        memcpy(&out4[i * 4 + 3], &prim, 4);
+    }
+    if (outNodeVisits) *outNodeVisits = c.st.nodeVisits;
+    if (outTriTests) *outTriTests = c.st.triTests;
+    return 0;
+}
+
 float oracle_random_float(uint32_t* state) { return pt_random_float(state); }
 
 float oracle_math(int fn, float x, float y)
@@ -1809,6 +1840,35 @@ void oracle_sample_brdf(const float* material, const float* V, const float* N, f
     f3 f = SampleBRDF(m, v, n, l, pdf, *rngState);
     outL[0] = l.x; outL[1] = l.y; outL[2] = l.z;
     outFPdf[0] = f.x; outFPdf[1] = f.y; outFPdf[2] = f.z; outFPdf[3] = pdf;
+}
+
+// Batch forms of the two probes above for the distribution tests of tests/test_oracle.py (per lobe: does the pdf that
+// EvalBRDF reports integrate to the probability of drawing a valid direction, and are the directions SampleBRDF draws
+// distributed as that pdf).  L: n x 3, out: n x 4 (f.xyz, pdf).
+void oracle_eval_brdf_batch(const float* material, const float* V, const float* N, float eta, const float* L, uint64_t n, float* out)
+{
+    f3 v = L3(V), nn = L3(N);
+    Material m = MaterialFromData(material, v, nn, eta);
+    for (uint64_t i = 0; i < n; i++) {
+        float pdf = 0.0f;
+        f3 f = EvalBRDF(m, v, nn, L3(L + 3 * i), pdf);
+        out[4 * i + 0] = f.x; out[4 * i + 1] = f.y; out[4 * i + 2] = f.z; out[4 * i + 3] = pdf;
+    }
+}
+
+// n consecutive SampleBRDF calls on ONE RNG chain (3 draws each, util/brdf.hlsl:247-249,258).  outL: n x 3, outFPdf: n x 4.
+void oracle_sample_brdf_batch(const float* material, const float* V, const float* N, float eta, uint32_t* rngState, uint64_t n,
+                              float* outL, float* outFPdf)
+{
+    f3 v = L3(V), nn = L3(N);
+    Material m = MaterialFromData(material, v, nn, eta);
+    for (uint64_t i = 0; i < n; i++) {
+        f3 l;
+        float pdf = 0.0f;
+        f3 f = SampleBRDF(m, v, nn, l, pdf, *rngState);
+        outL[3 * i + 0] = l.x; outL[3 * i + 1] = l.y; outL[3 * i + 2] = l.z;
+        outFPdf[4 * i + 0] = f.x; outFPdf[4 * i + 1] = f.y; outFPdf[4 * i + 2] = f.z; outFPdf[4 * i + 3] = pdf;
+    }
 }
 
 } // extern "C"

@@ -73,6 +73,9 @@ void     oracle_sample_brdf(const float* material, const float* V, const float* 
  *   what 2: EvalEnvMap(in[3k..3k+2], intensity 1)                       -> out[4k..4k+3]     (rgb, pdf)
  *   what 3: SampleEnvMap with rngState = (uint)in[k] bits               -> out[8k..8k+7]     (dir xyz, pdf, colour rgb, 0)
  * Returns EnvironmentCdfSum. */
+int oracle_trace_uv(const PTSceneDesc* scene, const OracleRay* rays, uint64_t n, float* out4, uint64_t* outNodeVisits, uint64_t* outTriTests);
+void oracle_eval_brdf_batch(const float* material, const float* V, const float* N, float eta, const float* L, uint64_t n, float* out);
+void oracle_sample_brdf_batch(const float* material, const float* V, const float* N, float eta, uint32_t* rngState, uint64_t n, float* outL, float* outFPdf);
 float    oracle_env_probe(const PTSceneDesc* scene, const PTFrameParams* params, int what, const float* in, uint64_t n, float* out);
 
 /* Scene ingestion: one Dispatch of MeshProcessing.compute:59-139 (writes triangles [OutputTriangleStart, +TriangleCount) of both

@@ -4,6 +4,8 @@
   cwbvh_*.npz   byte-exact CWBVH node/triangle dumps and TLAS dumps produced by the REFERENCE plugin
                 (Assets/Plugins/Web/plugin.cpp compiled in place -> oracle/_ref), together with their inputs.
   trace_*.npz   rays + (t, prim) from the REFERENCE's tinybvh CPU walker BVH::Intersect (oracle/ref_driver.cpp).
+  trace_cwbvh_*.npz  rays + (t, u, v, prim) from the REFERENCE's own CWBVH walker BVH8_CWBVH::Intersect
+                (oracle/ref_driver_cwbvh.cpp) -- the CPU twin of the shader's RayIntersectBvh.
   frame_*.npz   frames rendered by the CPU oracle (regression pin of the restatement itself; the reference's
                 shader cannot be executed here, so these are NOT reference outputs -- see DESIGN.md).
 
@@ -28,6 +30,25 @@ def soup(rng, n, spread=10.0, size=1.0):
     out = np.zeros((n * 3, 4), np.float32)
     out[:, :3] = v.reshape(-1, 3)
     return out
+
+
+def gen_trace_cwbvh():
+    """trace_cwbvh_*.npz: rays + full hit records (t, u, v, prim) from the reference's OWN CWBVH walker,
+    BVH8_CWBVH::Intersect (tiny_bvh.h:7006-7114) through oracle/ref_driver_cwbvh.cpp, with the CRC-32 of the node and
+    triangle bytes that walker traversed (= the bytes BuildBVH must produce for the same scene)."""
+    import zlib
+    rng = np.random.RandomState(20261005)
+    for name, sc, box, nr in (("zoo", scenes.material_zoo(), ((-3.5, 0.2, -3.5), (3.5, 4.0, 3.5)), 4000),
+                              ("sponza03", scenes.sponza_atrium(tex_size=4, detail=0.3), ((-14, 0.3, -6.5), (14, 11, 6.5)), 6000)):
+        rays = np.zeros((nr, 8), np.float32)
+        rays[:, 0:3] = rng.uniform(box[0], box[1], (nr, 3))
+        d = rng.normal(0, 1, (nr, 3))
+        rays[:, 3:6] = d / np.linalg.norm(d, axis=1, keepdims=True)
+        rays[:, 6] = 1e5
+        rec, rn, rt = pyoracle.ref_cwbvh_trace(sc.vertices, rays)
+        np.savez_compressed(os.path.join(HERE, f"trace_cwbvh_{name}.npz"), rays=rays, records=rec,
+                            node_crc=np.uint32(zlib.crc32(rn.tobytes())), tri_crc=np.uint32(zlib.crc32(rt.tobytes())))
+        print(f"trace_cwbvh_{name}: {nr} rays, hits {int((rec[:, 3].view(np.uint32) != 0xFFFFFFFF).sum())}")
 
 
 def main():
@@ -79,6 +100,8 @@ def main():
     np.savez_compressed(os.path.join(HERE, "trace_zoo.npz"), rays=rays, t=t, prim=prim)
     print("trace_zoo:", n, "rays, hits", int((prim != 0xFFFFFFFF).sum()))
 
+    gen_trace_cwbvh()
+
     # oracle regression frames
     from unity_webgpu_pathtracer_amd import plugin
     for name, sc, w, hgt, spp, seed in (("cornell", scenes.cornell_box(), 32, 32, 2, 0x12345678),
@@ -122,4 +145,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 2 and sys.argv[1] == "--only":       # regenerate one family without touching the others
+        pyoracle.build(ref=True)
+        {"trace_cwbvh": gen_trace_cwbvh}[sys.argv[2]]()
+    else:
+        main()
