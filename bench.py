@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark: Mrays/s of the path-tracing hot path at 1920x1080, 8 spp (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1 is launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 under a launcher (WORLD_SIZE set, the driver's `python -m torch.distributed.run ... bench.py --gpus N`): this process is
+one rank.  N > 1 WITHOUT a launcher (`python bench.py --gpus 8`): bench.py starts `torch.distributed.run --nproc-per-node N`
+on itself as a CHILD process, before anything here has touched HIP, and relays the child's JSON line and exit code.
 
 A "step" is one progressive pass (one DispatchCompute of the reference, PathTracer.cs:251) over the whole
 1920x1080 frame at 8 samples per pixel: step k uses CurrentSample = 8k, RngSeedRoot_k = 0x12345678 + k*0x9E3779B9
@@ -31,9 +35,9 @@ import zlib
 
 import numpy as np
 
-# consecutive passes overlap on PT_WF_SETS streams; the HIP runtime maps streams onto this many hardware queues (default 4)
-# and streams that share a queue serialise.  Must be set before the first HIP call (the plugin sets the same default when
-# it is loaded first; here torch initialises HIP before the plugin is loaded).
+# consecutive passes overlap on several streams; the HIP runtime maps streams onto this many hardware queues (default 4) and
+# streams that share a queue serialise.  The host's choice, made before the first HIP call (the plugin never touches the
+# environment; it sizes its default number of passes in flight to this variable, PTSetPassesInFlight).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -97,12 +101,44 @@ def cpu_baseline(scene, width, height, spp, pt, budget_rays=1_500_000):
         reps += 1
     one = ref.ref_bvh_trace(h, flat.ctypes.data_as(C.c_void_p), min(n, 200_000), 1, None, None)
     ref.ref_bvh_destroy(h)
-    return {
+    out = {
         "value": round(n * reps / total / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "reference",
         "sample": (f"{n} rays (closest-hit + NEE shadow) traced by the oracle for nine {ww}x{wh}-pixel windows of pass 0 of this "
                    f"workload, x{reps} repeats; tinybvh BVH::Intersect/IsOccluded, scalar binned-SAH build {build_ms.value:.0f} ms; "
                    f"single thread {min(n, 200_000) / one / 1e6:.3f} Mrays/s; oracle ray generation {gen_s:.1f} s"),
     }
+    # second leg: the reference's OWN CWBVH walker, BVH8_CWBVH::Intersect (tiny_bvh.h:7006-7114; shadow rays go
+    # through its FALLBACK_SHADOW_QUERY = a full Intersect), over the IDENTICAL ray list
+    cw = pyoracle.load_ref_cwbvh()
+    if cw is not None:
+        bms = C.c_double()
+        h2 = cw.ref_cwbvh_build(verts.ctypes.data_as(C.c_void_p), scene.tri_count, C.byref(bms))
+        cw.ref_cwbvh_trace(h2, flat.ctypes.data_as(C.c_void_p), n, cores, None)          # warm
+        tot2, reps2 = 0.0, 0
+        while tot2 < 3.0 and reps2 < 50:
+            tot2 += cw.ref_cwbvh_trace(h2, flat.ctypes.data_as(C.c_void_p), n, cores, None)
+            reps2 += 1
+        one2 = cw.ref_cwbvh_trace(h2, flat.ctypes.data_as(C.c_void_p), min(n, 200_000), 1, None)
+        cw.ref_cwbvh_destroy(h2)
+        out["cwbvh_walker"] = {"value": round(n * reps2 / tot2 / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "reference",
+                               "single_thread": round(min(n, 200_000) / one2 / 1e6, 3),
+                               "sample": f"the same {n} rays x{reps2}; tinybvh BVH8_CWBVH::Intersect (scalar code in the AVX-enabled TU, "
+                                         f"scalar build pipeline {bms.value:.0f} ms, -ffp-contract=off)"}
+    # context: the full CPU oracle render of BASELINE.json configs[0] (Cornell box 256x256, 1 spp), all threads
+    try:
+        c1 = scenes.make_scene("cornell")
+        from unity_webgpu_pathtracer_amd import plugin as _plugin
+        cn, ct = _plugin.build_cwbvh(c1.vertices)
+        cb = pyoracle.SceneBuffers(c1, cn, ct)
+        cp = scenes.frame_params(c1, 256, 256, spp=1, current_sample=0, seed=SEED0)
+        t1 = time.time()
+        _, cst = pyoracle.render(cb, cp)
+        dt = time.time() - t1
+        out["oracle_c1"] = {"seconds": round(dt, 4), "mrays_per_s": round(cst.rays / dt / 1e6, 3),
+                            "what": "CPU oracle (port of the whole shader, all host threads), Cornell box 256x256, 1 spp"}
+    except Exception as e:
+        out["oracle_c1"] = {"error": str(e)}
+    return out
 
 
 def main():
@@ -123,7 +159,25 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alg-replay", action="store_true", help="profiling runs: skip the untimed full-counter replay (roofline.achieved is then null)")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads reported under 'other_workloads'")
+    ap.add_argument("--passes-in-flight", type=int, default=0, help="PTSetPassesInFlight: 0 = library default for GPU_MAX_HW_QUEUES, 1 = passes back to back")
+    ap.add_argument("--latency-steps", type=int, default=6, help="passes of the latency leg (host synchronises after every pass); 0 = skip")
+    ap.add_argument("--build-device", action="store_true", help="also render over the tree PTBuildBVHDevice builds on the GPU (reported under 'device_built_tree')")
+    ap.add_argument("--master-port", type=int, default=29671, help="rendezvous port when bench.py launches its own ranks")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: start the ranks ourselves, as a child, BEFORE this process touches HIP
+    # (a process that has initialised the GPU must never exec another program; a child process is fine)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.force_dist:
+        import subprocess
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(args.master_port), os.path.abspath(__file__)] + sys.argv[1:]
+        child = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+        text = child.stdout.decode(errors="replace")
+        lines = [l for l in text.splitlines() if l.startswith("{")]
+        sys.stdout.write(lines[-1] + "\n" if lines else text)
+        sys.stdout.flush()
+        sys.exit(child.returncode)
 
     import torch
     import torch.distributed as dist
@@ -151,12 +205,14 @@ def main():
 
     W, H, SPP = args.width, args.height, args.spp
 
-    def run_workload(name, steps, warmup, full):
+    def run_workload(name, steps, warmup, full, build_device=None):
         wl = WORKLOADS[name]
         scene = scenes.make_scene(wl["scene"], **wl["kw"])
         pt = PathTracer(scene, device=local_rank, width=W, height=H, samplesPerPass=SPP, maxRayBounces=args.bounces,
-                        rank=rank, world_size=world)
+                        rank=rank, world_size=world, build_device=build_device)
         pt.set_schedule(args.schedule)
+        if args.passes_in_flight:
+            pt.set_passes_in_flight(args.passes_in_flight)
         if args.wf_iterations:
             pt.set_wavefront_iterations(args.wf_iterations)
         frames = [torch.zeros((H, W, 4), dtype=torch.float32, device=device) for _ in range(2)]
@@ -239,7 +295,29 @@ def main():
             res["max_stack_depth"] = int(fs.maxStackDepth)
         if distributed and full:
             dist.barrier()
+        if full and rank == 0 and not distributed and args.latency_steps > 0:
+            # latency leg: what a host gets that consumes every frame before it asks for the next (the reference presents each
+            # pass: OnRenderImage -> DispatchCompute -> Blit, PathTracer.cs:251-272): one pass at a time, host sync after each
+            pt.set_stats_level(0)
+            pt.synchronize()
+            pt.reset_stats()
+            c2, t_lat = cur, []
+            for k in range(warmup + steps, warmup + steps + args.latency_steps):
+                p = scenes.frame_params(scene, W, H, spp=SPP, current_sample=k * SPP, seed=seed_of(k), max_bounces=args.bounces)
+                t1 = time.perf_counter()
+                pt.render_pass_to(p, frames[c2].data_ptr(), frames[1 - c2].data_ptr() if k > 0 else 0)
+                pt.synchronize()
+                t_lat.append(time.perf_counter() - t1)
+                c2 = 1 - c2
+            ls = pt.stats()
+            lat = sorted(t_lat)[len(t_lat) // 2]
+            res["latency_mode"] = {"ms_per_pass": round(lat * 1e3, 4), "mrays_per_s": round(ls.rays / len(t_lat) / lat / 1e6, 3),
+                                   "passes": len(t_lat), "ms_per_pass_all": [round(t * 1e3, 3) for t in t_lat],
+                                   "what": "median wall time of one pass when the host synchronises after every pass (enqueue + "
+                                           "device + hipStreamSynchronize): one pass in flight, as under the reference's "
+                                           "OnRenderImage -> Blit (PathTracer.cs:251-272); `value` keeps several passes in flight"}
         res["schedule"] = pt.schedule()
+        res["passes_in_flight"] = pt.passes_in_flight()
         res["_pt"], res["_scene"] = pt, scene
         return res
 
@@ -284,6 +362,7 @@ def main():
                                    f"progressive passes (CurrentSample = 8k)",
                        "tris": main_res["tris"], "rays_per_step": round(main_res["rays_per_step"]),
                        "msamples_per_s": round(main_res["msamples_per_s"], 3), "schedule": main_res["schedule"],
+                       "passes_in_flight": main_res["passes_in_flight"],
                        "frame_crc32": main_res["frame_crc32"],
                        "sharding": "interleaved 16x16 blocks, one RCCL gather of owned tiles per frame" if distributed else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -299,6 +378,24 @@ def main():
                                  "the scene is Infinity-Cache resident, so HBM is the nominal roof only: the pass is bound by VALU issue at 40-55 % lane "
                                  "utilisation (valu_issue.frac), with the texture-data path ~70 % busy (DESIGN.md 5.4)"},
         }
+    if out is not None and "latency_mode" in main_res:
+        out["latency_mode"] = main_res["latency_mode"]
+    if args.build_device and not distributed and out is not None:
+        # the same workload over the tree the MI355X builds itself (PTBuildBVHDevice: LBVH -> 8-wide collapse -> CWBVH encode),
+        # against the reference-identical binned-SAH tree of the main run: throughput and traversal work per ray
+        main_res["_pt"].close()
+        main_res["_pt"] = None
+        r = run_workload(args.workload, max(4, args.steps // 2), max(2, args.warmup), full=True, build_device=local_rank)
+        c_dev, c_sah = r.get("counters_per_launch", {}), main_res.get("counters_per_launch", {})
+        rays_dev, rays_sah = max(1.0, r["rays_per_step"]), max(1.0, main_res["rays_per_step"])
+        out["device_built_tree"] = {
+            "mrays_per_s": round(r["mrays_per_s"], 3), "ms_per_step": round(r["ms_per_step"], 4),
+            "vs_sah_tree": round(r["mrays_per_s"] / main_res["mrays_per_s"], 4),
+            "node_visits_per_ray": round(c_dev.get("nodeVisits", 0) / rays_dev, 3), "tri_tests_per_ray": round(c_dev.get("triTests", 0) / rays_dev, 3),
+            "sah_node_visits_per_ray": round(c_sah.get("nodeVisits", 0) / rays_sah, 3), "sah_tri_tests_per_ray": round(c_sah.get("triTests", 0) / rays_sah, 3),
+            "nodes": int(r["_pt"]._bvhScene.bvh_nodes.nbytes // 80), "build_ms": r["_pt"]._bvhScene.build_ms,
+            "what": "PTBuildBVHDevice tree (hit-equal, not byte-equal, to BuildBVH's): frames differ only where ties are broken differently"}
+        r["_pt"].close()
     if not args.no_extra and not distributed:
         extra = {}
         for name in WORKLOADS:
@@ -315,7 +412,6 @@ def main():
         scene = main_res.get("_scene")
         pt = main_res.get("_pt")
         if pt is None:
-            scene = scenes.make_scene(wl["scene"], **wl["kw"])
             pt = PathTracer(scene, device=local_rank, width=W, height=H, samplesPerPass=SPP)
         try:
             out["cpu_baseline"] = cpu_baseline(scene, W, H, SPP, pt)

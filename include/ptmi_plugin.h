@@ -325,6 +325,16 @@ PT_API int PTGetSchedule(PTContext* ctx);
  * work between the wavefront kernels and the cleanup kernel (tuning / test knob). */
 PT_API int PTSetWavefrontIterations(PTContext* ctx, int iterations);
 
+/* Wavefront schedules: how many consecutive passes may be in flight at once, each on its own path-state set and HIP stream
+ * (the pixel write of a pass is decoupled from its path loop, so pass k+1 traces while pass k drains; only the resolves are
+ * ordered).  1 = passes run back to back (what a host that reads every frame back gets anyway).  0 (default) = sized to the
+ * hardware queues the host asked the HIP runtime for: GPU_MAX_HW_QUEUES >= 16 -> 12, >= 8 -> 6, otherwise 3 (streams that
+ * share a hardware queue serialise; the library never changes the environment itself).  Each set costs ~290 B per owned pixel
+ * and is allocated on the first pass that can use it; lowering the number frees the sets no longer used.  Same frame for
+ * every value. */
+PT_API int PTSetPassesInFlight(PTContext* ctx, int passes);
+PT_API int PTGetPassesInFlight(PTContext* ctx);
+
 /* Text of the last error on the calling thread ("" if none). */
 PT_API const char* PTGetLastError(void);
 /* Library/ABI version: (major << 16) | minor. */

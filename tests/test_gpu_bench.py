@@ -37,6 +37,14 @@ def test_bench_contract_and_two_rank_rehearsal():
     assert two["n_gpus"] == 2 and two["value"] > 0
     assert two["config"]["rays_per_step"] == one["config"]["rays_per_step"]          # strong scaling: same frame, same rays
     assert two["config"]["frame_crc32"] == one["config"]["frame_crc32"] != 0
+    # `python bench.py --gpus 2` WITHOUT an outer launcher: bench.py starts its own ranks as a child process and relays the line
+    env2 = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    self_launched = _last_json(subprocess.check_output(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device", "--master-port", "29613"] + SMALL,
+        env=env2, timeout=900, stderr=subprocess.STDOUT))
+    assert self_launched["n_gpus"] == 2 and self_launched["config"]["frame_crc32"] == one["config"]["frame_crc32"]
+    # N = 1 carries the latency leg (host sync after every pass) next to the pipelined throughput
+    assert one["latency_mode"]["ms_per_pass"] > 0 and one["latency_mode"]["passes"] >= 1
 
 
 @pytest.mark.gpu

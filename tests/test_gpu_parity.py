@@ -563,6 +563,21 @@ def test_scene_with_bad_indices_is_refused():
     tris[2, 3] = 0x00FFFFFF                                        # primitive index of triangle 0
     d = bs.desc(); d.bvhTris = tris.ctypes.data
     refused(d, "primitive index")
+    # round 3 (ADVICE): a child the KERNEL treats as inner (meta bits 3 and 4 set) but whose upper bits are not 001, hidden behind
+    # imask == 0: validation must decode the byte as cwbvh_node_hitmask does, not as the builder writes it
+    nodes = np.frombuffer(bs.bvh_nodes.tobytes(), abi.CWBVH_NODE).copy()
+    nodes["meta"][leafy][0] = 0x58
+    d = bs.desc(); d.bvhNodes = nodes.ctypes.data
+    refused(d, "inner child whose meta byte")
+    nodes = np.frombuffer(bs.bvh_nodes.tobytes(), abi.CWBVH_NODE).copy()
+    nodes["childBaseIndex"][k] = 0                                 # a child pointer that points back at the root: traversal would never end
+    d = bs.desc(); d.bvhNodes = nodes.ctypes.data
+    refused(d, "reachable twice")
+    nodes = np.frombuffer(bs.bvh_nodes.tobytes(), abi.CWBVH_NODE).copy()
+    nodes["meta"][leafy][:] = 0
+    nodes["meta"][leafy][0] = (7 << 5) | 23                        # three triangle bits starting at bit 23: they leave the 24-bit mask
+    d = bs.desc(); d.bvhNodes = nodes.ctypes.data
+    refused(d, "leave the 24-bit mask")
     pt.render_pass(pt.params(seed=1))                              # the old scene is still there and still renders the same bits
     assert np.array_equal(pt.readback().view(np.uint32), good.view(np.uint32))
     pt.close()
@@ -578,6 +593,14 @@ def test_scene_with_bad_indices_is_refused():
     tl.view(np.uint32)[bs.tlas_index_offset] = 99
     d = bs.desc(); d.tlasData = tl.ctypes.data
     refused(d, "TLAS index")
+    tl = bs.tlas_data.copy()
+    inner = [n for n in range(bs.tlas_index_offset // 16) if tl.view(np.uint32)[n * 16 + 11] == 0]
+    tl.view(np.uint32)[inner[-1] * 16 + 3] = 0                     # left child of an inner TLAS node -> the root: a cycle
+    d = bs.desc(); d.tlasData = tl.ctypes.data
+    refused(d, "TLAS node 0 is reachable twice")
+    d = bs.desc(); d.tlasIndexOffset = 0
+    rc = lib.PTSetScene(pt.ctx, C.byref(d))
+    assert rc == abi.PT_ERR_INVALID_ARG
     pt.close()
 
 

@@ -281,6 +281,17 @@ def test_glb_roundtrip(tmp_path, interleave):
             assert np.array_equal(got.indices.reshape(-1, 3)[:, ::-1].reshape(-1).astype(np.int64), src.indices.astype(np.int64))
         f = np.diag([1.0, 1.0, -1.0, 1.0])
         assert np.allclose(got.local_to_world, f @ mat @ f)
+    # the mirrored axis is a parameter (which one UnityGLTF 2.14.1 uses is unpinned: its source is not in the reference tree)
+    xflip, _, _ = ingest.load_glb(path, flip_axis=0, flip_v=True)
+    for src, got, mat in zip(meshes, xflip, mats):
+        if src.indices is not None:
+            assert np.array_equal(got.positions[:, 0], -src.positions[:, 0]) and np.array_equal(got.positions[:, 1:], src.positions[:, 1:])
+            if src.uvs is not None:
+                assert np.array_equal(got.uvs[:, 0], src.uvs[:, 0]) and np.allclose(got.uvs[:, 1], 1.0 - src.uvs[:, 1])
+        f = np.diag([-1.0, 1.0, 1.0, 1.0])
+        assert np.allclose(got.local_to_world, f @ mat @ f)
+    with pytest.raises(ValueError):
+        ingest.load_glb(path, flip_axis=3)
     packed = ingest.pack_gltf_materials(materials)
     assert packed.shape == (3, 32) and np.allclose(packed[0, :3], [0.5, 0.25, 1.0], rtol=1e-5) and packed[1, 12] == 1.0 and packed[1, 7] == np.float32(0.3)
 

@@ -186,7 +186,8 @@ struct WideArgs {
     const uint32_t *left, *right, *first, *last;
     uint32_t n;
     uint32_t* wideRoot;         // [wide node] binary reference it was made from
-    uint32_t* counters;         // [0] wide nodes allocated, [1] triangle rows (float4) allocated
+    uint32_t maxWide;           // capacity of the wide-node pool (nodes, wideRoot)
+    uint32_t* counters;         // [0] wide nodes allocated, [1] triangle rows (float4) allocated, [2] pool-overflow flag
     uint4* nodes;               // PTCwbvhNode as 5 x uint4
     float4* tris;               // PTCwbvhTri as 3 x float4
 };
@@ -284,6 +285,9 @@ __global__ __launch_bounds__(64) void pt_cwbvh_level(WideArgs A, uint32_t levelS
     }
     const uint32_t childBase = numInner ? atomicAdd(&A.counters[0], numInner) : 0u;
     const uint32_t triBase = numTris ? atomicAdd(&A.counters[1], numTris * 3u) : 0u;
+    // pool overflow (cannot happen for a well-formed hierarchy: < 2n wide nodes, exactly 3n triangle rows): write nothing past the
+    // pools, leave a flag for the host, which fails the build
+    if (childBase + numInner > A.maxWide || triBase + numTris * 3u > 3u * A.n) { atomicOr(&A.counters[2], 1u); return; }
     // ---- encode
     const int ex = quant_exponent(nb.mx[0] - nb.mn[0]), ey = quant_exponent(nb.mx[1] - nb.mn[1]), ez = quant_exponent(nb.mx[2] - nb.mn[2]);
     const float px = ldexpf(1.0f, ex), py = ldexpf(1.0f, ey), pz = ldexpf(1.0f, ez);
@@ -358,6 +362,9 @@ bool build_cwbvh_device(int device, const PTFloat4* verts, uint32_t n, Cwbvh& ou
     if (n > 0x7FFFFFF0u / 3u) { err = "too many triangles"; return false; }
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) { err = "no such HIP device (this builder has no CPU fallback; BuildBVH is the CPU builder)"; return false; }
+    // the calling thread's current device is left as it was found
+    struct DeviceGuard { int prev = -1; ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); } } dguard;
+    if (hipGetDevice(&dguard.prev) != hipSuccess) dguard.prev = -1;
     GPU_TRY(hipSetDevice(device));
     hipStream_t stream;
     GPU_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -382,8 +389,11 @@ bool build_cwbvh_device(int device, const PTFloat4* verts, uint32_t n, Cwbvh& ou
     GPU_TRY(hipMemcpyAsync(dScene, sceneInit, sizeof(sceneInit), hipMemcpyHostToDevice, stream));
     GPU_TRY(hipMemsetAsync(dVisits, 0, (size_t)n * 4, stream));
     const uint32_t blocks = (n + 255u) / 256u;
+    // a launch that fails (no code object for this device, bad configuration) leaves its outputs untouched: check every one
     hipLaunchKernelGGL(pt_lbvh_bounds, dim3(blocks), dim3(256), 0, stream, dVerts, n, dPrim, dScene);
+    GPU_TRY(hipGetLastError());
     hipLaunchKernelGGL(pt_lbvh_morton, dim3(blocks), dim3(256), 0, stream, dPrim, n, dScene, dKeys, dIds);
+    GPU_TRY(hipGetLastError());
     {
         size_t tempBytes = 0;
         GPU_TRY(rocprim::radix_sort_pairs(nullptr, tempBytes, dKeys, dKeysSorted, dIds, dIdsSorted, n, 0, 63, stream));
@@ -395,27 +405,41 @@ bool build_cwbvh_device(int device, const PTFloat4* verts, uint32_t n, Cwbvh& ou
     if (n > 1) {
         Tree t{dKeysSorted, n};
         hipLaunchKernelGGL(pt_lbvh_hierarchy, dim3((n - 1 + 255u) / 256u), dim3(256), 0, stream, t, dLeft, dRight, dParentI, dParentL, dFirst, dLast);
+        GPU_TRY(hipGetLastError());
         hipLaunchKernelGGL(pt_lbvh_fit, dim3(blocks), dim3(256), 0, stream, n, dIdsSorted, dPrim, dLeft, dRight, dParentI, dParentL, dNodeBox, dVisits);
+        GPU_TRY(hipGetLastError());
         rootRef = 0u;
     }
     // level 0 = the root wide node
     const uint32_t countersInit[4] = {1u, 0u, 0u, 0u};
     GPU_TRY(hipMemcpyAsync(dCounters, countersInit, sizeof(countersInit), hipMemcpyHostToDevice, stream));
     GPU_TRY(hipMemcpyAsync(dWideRoot, &rootRef, 4, hipMemcpyHostToDevice, stream));
-    WideArgs A{dVerts, dIdsSorted, dPrim, dNodeBox, dLeft, dRight, dFirst, dLast, n, dWideRoot, dCounters, dNodes, dTris};
+    WideArgs A{dVerts, dIdsSorted, dPrim, dNodeBox, dLeft, dRight, dFirst, dLast, n, dWideRoot, (uint32_t)maxWide, dCounters, dNodes, dTris};
     uint32_t levelStart = 0, levelEnd = 1, levels = 0;
     while (levelStart < levelEnd) {
         if (levelEnd > maxWide) { err = "wide-node pool exhausted"; return false; }
         hipLaunchKernelGGL(pt_cwbvh_level, dim3((levelEnd - levelStart + 63u) / 64u), dim3(64), 0, stream, A, levelStart, levelEnd);
+        GPU_TRY(hipGetLastError());
         uint32_t allocated = 0;
         GPU_TRY(hipMemcpyAsync(&allocated, dCounters, 4, hipMemcpyDeviceToHost, stream));
         GPU_TRY(hipStreamSynchronize(stream));
+        if (allocated < levelEnd || allocated > maxWide) { err = "wide-node pool exhausted or corrupted (allocated " + std::to_string(allocated) + " of " + std::to_string(maxWide) + ")"; return false; }
         levelStart = levelEnd;
         levelEnd = allocated;
         if (++levels > 4096u) { err = "tree depth out of range"; return false; }
     }
     GPU_TRY(hipEventRecord(e1, stream));
     const uint32_t wideCount = levelEnd;
+    {
+        // every triangle must have been emitted exactly once (counters[1] = triangle rows written), at least the root node exists
+        uint32_t counters[4] = {0, 0, 0, 0};
+        GPU_TRY(hipMemcpyAsync(counters, dCounters, sizeof(counters), hipMemcpyDeviceToHost, stream));
+        GPU_TRY(hipStreamSynchronize(stream));
+        if (wideCount < 1u || counters[1] != 3u * n || counters[2] != 0u) {
+            err = "device build incomplete: " + std::to_string(wideCount) + " nodes, " + std::to_string(counters[1]) + " triangle rows for " + std::to_string(n) + " triangles";
+            return false;
+        }
+    }
     out.triCount = n;
     out.usedBlocks = wideCount * 5u;
     out.nodeData.assign((size_t)wideCount * 5, PTFloat4{0, 0, 0, 0});

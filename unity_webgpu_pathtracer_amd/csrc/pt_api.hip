@@ -6,10 +6,11 @@
 // There is NO CPU fallback: without a HIP device PTCreate fails with PT_ERR_NO_DEVICE.
 #include "pt_launch.h"
 
-#include <rocprofiler-sdk-roctx/roctx.h>      // ranges around every pass / scene upload / build: rocprofv3 --marker-trace shows them
+#include <dlfcn.h>
 
 #include <cstdio>
 #include <cstdlib>
+#include <array>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -17,12 +18,38 @@
 
 namespace {
 
-// Consecutive passes run on PT_WF_SETS streams so that one pass's launch tails are filled by its neighbours' kernels.  The
-// HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, one of them the context stream's):
-// streams that share a queue serialise.  Ask for 16 (12 set streams + the context stream) unless the host has already chosen; this runs when the library is loaded,
-// i.e. before the first HIP call of a host that loads the plugin first (a host that has initialised HIP already keeps its
-// own setting -- bench.py therefore sets the variable itself before importing torch).
-__attribute__((constructor)) void pt_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// Consecutive passes run on up to PT_WF_SETS streams so that one pass's launch tails are filled by its neighbours' kernels.
+// The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, one of them the context stream's) and
+// streams that share a queue serialise: more sets than queues is SLOWER than fewer sets.  The library never
+// touches the host's environment: it reads the variable the host chose (export GPU_MAX_HW_QUEUES=16 before
+// the first HIP call; bench.py, host/pt_host.c and the Python mirror do) and sizes the default number of passes in flight
+// to it: >= 16 queues -> 12 sets, >= 8 -> 6, otherwise 3.  PTSetPassesInFlight overrides.
+uint32_t default_passes_in_flight()
+{
+    const char* e = getenv("GPU_MAX_HW_QUEUES");
+    const long q = e ? strtol(e, nullptr, 10) : 4;
+    uint32_t n = q >= 16 ? 12u : (q >= 8 ? 6u : 3u);
+    return n < (uint32_t)PT_WF_SETS ? n : (uint32_t)PT_WF_SETS;
+}
+
+// roctx ranges around every pass / scene upload (rocprofv3 --marker-trace shows them; the reference wraps its dispatch in
+// _cmd.BeginSample / EndSample("Path Tracer"), PathTracer.cs:226,252).  Resolved lazily: a host on a runtime-only ROCm install
+// without librocprofiler-sdk-roctx still loads the plugin, and the ranges are no-ops.
+struct RoctxApi {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    RoctxApi()
+    {
+        void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_LAZY | RTLD_GLOBAL);
+        if (!h) h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_LAZY | RTLD_GLOBAL);
+        if (!h) h = dlopen("/opt/rocm/lib/librocprofiler-sdk-roctx.so", RTLD_LAZY | RTLD_GLOBAL);
+        if (!h) return;
+        push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+        pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (!push || !pop) { push = nullptr; pop = nullptr; }
+    }
+};
+const RoctxApi& roctx_api() { static RoctxApi api; return api; }
 
 thread_local std::string g_lastError;
 
@@ -47,9 +74,9 @@ struct DeviceBuffer {
 
 struct EventPair { hipEvent_t start, stop; uint32_t launches; };
 
-struct RoctxRange {                      // the reference wraps its dispatch in _cmd.BeginSample / EndSample("Path Tracer") (PathTracer.cs:226,252)
-    explicit RoctxRange(const char* name) { roctxRangePushA(name); }
-    ~RoctxRange() { roctxRangePop(); }
+struct RoctxRange {
+    explicit RoctxRange(const char* name) { if (roctx_api().push) roctx_api().push(name); }
+    ~RoctxRange() { if (roctx_api().pop) roctx_api().pop(); }
 };
 
 } // namespace
@@ -82,6 +109,7 @@ struct PTContext {
         hipEvent_t callEv = nullptr, done = nullptr;
     } sets[PT_WF_SETS];
     uint32_t nextSet = 0;
+    uint32_t numSets = 0;                       // passes in flight = state sets in use (PTSetPassesInFlight); carved on first use
     uint32_t wfIterations = 0;                  // 0 = automatic
 };
 
@@ -128,11 +156,17 @@ int ensure_wavefront(PTContext* c, PTContext::WfSet& set, uint32_t numSlots, uin
     const size_t n = numSlots;
     const uint32_t numRows = 4u * (numSlots >> 6);
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t spillBytes = n * (size_t)(PT_BVH_STACK_SIZE - PT_WF_LDS_STACK) * sizeof(uint2);
-    const size_t suspBytes = (n >> 6) * (size_t)PT_WF_SUSPEND_MAX * 6 * sizeof(uint4);
-    const size_t tlasSpillBytes = needTlas ? n * (size_t)PT_BVH_STACK_SIZE * sizeof(uint32_t) : 0;
+    // trace waves own 64 or 128 consecutive slots (pt_wf_wide_ranges); a wave addresses 64 slab rows and PT_WF_SUSPEND records
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+    const uint32_t residentWaves = (uint32_t)prop.multiProcessorCount * 4u * 8u;
+    // the HAS_TLAS refill kernel always uses PT_WF_RANGE = 128 slots per wave; the plain one 64 or 128 (pt_wf_wide_ranges)
+    const size_t traceWaves = pt_wf_max_trace_waves(numSlots, residentWaves);
+    const size_t spillBytes = traceWaves * 64u * (size_t)(PT_BVH_STACK_SIZE - PT_WF_LDS_STACK) * sizeof(uint2);
+    const size_t suspBytes = traceWaves * (size_t)(PT_WF_SUSPEND ? PT_WF_SUSPEND : 1u) * 6 * sizeof(uint4);
+    const size_t tlasSpillBytes = needTlas ? traceWaves * 64u * (size_t)PT_BVH_STACK_SIZE * sizeof(uint32_t) : 0;
     size_t total = align(n * 4) * 2 + align(n * 16) * 13 + align(n * 2) + align((size_t)maxIterations * 4) +
-                   align((size_t)numRows * 16 * 8) + align(8 * 32 * 4) + align(spillBytes) + align(suspBytes) + align((n >> 6) * 4) + align(tlasSpillBytes);
+                   align((size_t)numRows * 16 * 8) + align(8 * 32 * 4) + align(spillBytes) + align(suspBytes) + align(traceWaves * 4) + align(tlasSpillBytes);
     if (set.arena && set.arenaBytes < total) { hipFree(set.arena); set.arena = nullptr; set.arenaBytes = 0; }
     if (!set.arena) {
         HIP_TRY(hipMalloc(&set.arena, total));
@@ -153,13 +187,9 @@ int ensure_wavefront(PTContext* c, PTContext::WfSet& set, uint32_t numSlots, uin
     B.chunkHeads = (uint32_t*)carve(8 * 32 * 4);
     B.stackSpill = (uint2*)carve(spillBytes);
     B.susp = (uint4*)carve(suspBytes);
-    B.suspCount = (uint32_t*)carve((n >> 6) * 4);
+    B.suspCount = (uint32_t*)carve(traceWaves * 4);
     B.tlasSpill = needTlas ? (uint32_t*)carve(tlasSpillBytes) : nullptr;
-    {
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, c->device));
-        B.residentWaves = (uint32_t)prop.multiProcessorCount * 4u * 8u;
-    }
+    B.residentWaves = residentWaves;
     B.numSlots = numSlots;
     B.numStatRows = numRows;
     B.maxIterations = maxIterations;
@@ -199,85 +229,99 @@ bool validate_scene(const PTSceneDesc& s, std::string& why)
             memcpy(&mi, attrs + i * 128 + 120, 4);
             if (mi >= s.materialCount) return bad("triangle " + std::to_string(i) + ": materialIndex " + std::to_string(mi) + " >= materialCount");
         }
-    // CWBVH: children, triangle rows, primitive indices.  With HAS_TLAS the arrays hold several BLASes back to back and every
-    // instance adds its own offsets: check each instance's range (below) and each node relative to the WHOLE arrays here.
+    // CWBVH: children, triangle rows, primitive indices -- decoded EXACTLY as the kernels decode them (cwbvh_node_hitmask,
+    // pt_device.h): a child is inner iff bits 3 and 4 of its meta byte are both set, whatever the upper bits say; a leaf's
+    // triangle bits are (meta >> 5) & 7 shifted to bit (meta & 31).  Every BLAS is walked from its root with a visited map, so a
+    // child pointer that points back (a cycle: traversal would never end) or sideways (two parents) is refused, and only what
+    // a ray can reach has to be in range.  With HAS_TLAS the arrays hold several BLASes back to back; every distinct
+    // (bvhOffset, triOffset, triAttributeOffset) triple is walked once.
     const uint8_t* nodes = (const uint8_t*)s.bvhNodes;
     const float* tris = (const float*)s.bvhTris;
-    for (uint64_t n = 0; n < nodeCount; ++n) {
-        const uint8_t* p = nodes + n * 80;
-        uint32_t childBase, triBase;
-        memcpy(&childBase, p + 16, 4);
-        memcpy(&triBase, p + 20, 4);
-        const uint8_t imask = p[15];
-        const uint8_t* meta = p + 24;
-        uint32_t inner = 0, maxTriRow = 0;
-        bool anyLeaf = false;
-        for (int i = 0; i < 8; ++i) {
-            const uint32_t m = meta[i];
-            if (m == 0) continue;
-            if ((m & 0x18u) == 0x18u && (m >> 5) == 1u) { inner++; continue; }      // inner: (1 << 5) | (24 + slot)
-            anyLeaf = true;
-            const uint32_t first = m & 31u, count = (uint32_t)__builtin_popcount(m >> 5);
-            const uint32_t last = (first + count) * 3u;
-            if (last > maxTriRow) maxTriRow = last;
+    std::vector<uint8_t> seen(nodeCount, 0);
+    auto walk_blas = [&](uint64_t nodeOff, uint64_t triOff, uint64_t attrOff, const std::string& who) -> bool {
+        std::vector<uint32_t> todo(1, 0u);
+        std::vector<uint64_t> touched;
+        bool ok = true;
+        while (ok && !todo.empty()) {
+            const uint32_t rel = todo.back();
+            todo.pop_back();
+            const uint64_t n = nodeOff + rel;
+            if (n >= nodeCount) { ok = bad(who + ": child index past the node array"); break; }
+            if (seen[n]) { ok = bad(who + ": node " + std::to_string(n) + " is reachable twice (the node graph is not a tree)"); break; }
+            seen[n] = 1;
+            touched.push_back(n);
+            const uint8_t* p = nodes + n * 80;
+            uint32_t childBase, triBase;
+            memcpy(&childBase, p + 16, 4);
+            memcpy(&triBase, p + 20, 4);
+            const uint8_t imask = p[15];
+            uint32_t inner = 0;
+            for (int k = 0; k < 8 && ok; ++k) {
+                const uint32_t m = p[24 + k];
+                if (m == 0) continue;
+                if ((m & 0x18u) == 0x18u) {
+                    // the kernel shifts (meta >> 5) & 7 to bit 24 + slot: anything but 1 sets the hit bit of ANOTHER slot
+                    if ((m >> 5) != 1u) { ok = bad(who + ": node " + std::to_string(n) + " has an inner child whose meta byte is not (1 << 5) | (24 + slot)"); break; }
+                    if ((uint64_t)childBase + inner >= 0xFFFFFFFFull) { ok = bad(who + ": child index overflow"); break; }
+                    todo.push_back(childBase + inner);
+                    inner++;
+                    continue;
+                }
+                const uint32_t first = m & 31u, bits = (m >> 5) & 7u;
+                if (bits == 0u) continue;
+                const uint32_t top = first + (31u - (uint32_t)__builtin_clz(bits));        // highest triangle bit of the 24-bit triangle mask
+                if (top >= 24u) { ok = bad(who + ": node " + std::to_string(n) + " has a leaf whose triangle bits leave the 24-bit mask"); break; }
+                for (uint32_t q = first; q <= top; ++q) {
+                    if (!((bits >> (q - first)) & 1u)) continue;
+                    const uint64_t row = triOff + triBase + (uint64_t)q * 3u;
+                    if (row + 2 >= triRows) { ok = bad(who + ": triangle rows past the triangle array"); break; }
+                    uint32_t prim;
+                    memcpy(&prim, tris + (row + 2) * 4 + 3, 4);
+                    if (attrOff + prim >= attrCount) { ok = bad(who + ": primitive index " + std::to_string(prim) + " has no attribute record"); break; }
+                }
+            }
+            if (ok && inner != (uint32_t)__builtin_popcount(imask)) ok = bad(who + ": node " + std::to_string(n) + ": imask does not match its inner children");
         }
-        if (inner != (uint32_t)__builtin_popcount(imask)) return bad("node " + std::to_string(n) + ": imask does not match its inner children");
-        if (!tlasOn) {
-            if (inner && (uint64_t)childBase + inner > nodeCount) return bad("node " + std::to_string(n) + ": child index past the node array");
-            if (anyLeaf && (uint64_t)triBase + maxTriRow > triRows) return bad("node " + std::to_string(n) + ": triangle rows past the triangle array");
-        }
-    }
-    if (!tlasOn)
-        for (uint64_t t = 0; t + 2 < triRows; t += 3) {
-            uint32_t prim;
-            memcpy(&prim, tris + (t + 2) * 4 + 3, 4);
-            if (prim >= attrCount) return bad("triangle row " + std::to_string(t) + ": primitive index " + std::to_string(prim) + " has no attribute record");
-        }
-    if (tlasOn) {
+        if (tlasOn) for (uint64_t n : touched) seen[n] = 0;          // BLASes may share nodes between instances, never within one
+        return ok;
+    };
+    if (!tlasOn) {
+        if (!walk_blas(0, 0, 0, "BVH")) return false;
+    } else {
+        if (s.tlasIndexOffset < 16u) return bad("tlasIndexOffset < 16: HAS_TLAS needs at least one TLAS node");
         const uint64_t tlasNodes = s.tlasIndexOffset / 16u, indices = s.tlasDataFloats - s.tlasIndexOffset;
         const uint32_t* T = (const uint32_t*)s.tlasData;
-        for (uint64_t n = 0; n < tlasNodes; ++n) {
-            const uint32_t left = T[n * 16 + 3], right = T[n * 16 + 7], count = T[n * 16 + 11], first = T[n * 16 + 15];
-            if (count == 0) { if (left >= tlasNodes || right >= tlasNodes) return bad("TLAS node " + std::to_string(n) + ": child index past the TLAS nodes"); }
-            else if ((uint64_t)first + count > indices) return bad("TLAS node " + std::to_string(n) + ": instance range past the index list");
+        // the 2-wide TLAS is walked from node 0 as the kernel walks it (tlas.hlsl:246-331): children in range, no node twice
+        {
+            std::vector<uint8_t> seenT(tlasNodes, 0);
+            std::vector<uint32_t> todo(1, 0u);
+            while (!todo.empty()) {
+                const uint32_t n = todo.back();
+                todo.pop_back();
+                if (n >= tlasNodes) return bad("TLAS child index " + std::to_string(n) + " past the TLAS nodes");
+                if (seenT[n]) return bad("TLAS node " + std::to_string(n) + " is reachable twice (the TLAS is not a tree)");
+                seenT[n] = 1;
+                const uint32_t left = T[(size_t)n * 16 + 3], right = T[(size_t)n * 16 + 7], count = T[(size_t)n * 16 + 11], first = T[(size_t)n * 16 + 15];
+                if (count == 0) { todo.push_back(left); todo.push_back(right); }
+                else if ((uint64_t)first + count > indices) return bad("TLAS node " + std::to_string(n) + ": instance range past the index list");
+            }
         }
         for (uint64_t i = 0; i < indices; ++i)
             if (T[s.tlasIndexOffset + i] >= s.instanceCount) return bad("TLAS index " + std::to_string(i) + " >= instanceCount");
         const uint8_t* inst = (const uint8_t*)s.gpuInstances;
+        std::vector<std::array<int32_t, 3>> walked;                  // distinct BLASes already validated
         for (uint32_t i = 0; i < s.instanceCount; ++i) {
             int32_t off[4];
             memcpy(off, inst + (size_t)i * 144 + 128, 16);
             if (off[0] < 0 || (uint64_t)off[0] >= nodeCount || off[1] < 0 || (uint64_t)off[1] > triRows || off[2] < 0 || (uint64_t)off[2] > attrCount ||
                 off[3] < 0 || (uint32_t)off[3] >= s.materialCount)
                 return bad("instance " + std::to_string(i) + ": bvhOffset / triOffset / triAttributeOffset / materialIndex out of range");
-            // walk the instance's BLAS from its root: every node, triangle row and primitive index it can reach must exist
-            std::vector<uint32_t> todo(1, 0u);
-            uint64_t visited = 0;
-            while (!todo.empty()) {
-                const uint32_t rel = todo.back();
-                todo.pop_back();
-                if (++visited > nodeCount) return bad("instance " + std::to_string(i) + ": BLAS node graph is not a tree");
-                const uint64_t n = (uint64_t)off[0] + rel;
-                if (n >= nodeCount) return bad("instance " + std::to_string(i) + ": BLAS child index past the node array");
-                const uint8_t* p = nodes + n * 80;
-                uint32_t childBase, triBase;
-                memcpy(&childBase, p + 16, 4);
-                memcpy(&triBase, p + 20, 4);
-                uint32_t inner = 0;
-                for (int k = 0; k < 8; ++k) {
-                    const uint32_t m = p[24 + k];
-                    if (m == 0) continue;
-                    if ((m & 0x18u) == 0x18u && (m >> 5) == 1u) { todo.push_back(childBase + inner); inner++; continue; }
-                    const uint32_t first = m & 31u, count = (uint32_t)__builtin_popcount(m >> 5);
-                    for (uint32_t q = first; q < first + count; ++q) {
-                        const uint64_t row = (uint64_t)off[1] + triBase + (uint64_t)q * 3u;
-                        if (row + 2 >= triRows) return bad("instance " + std::to_string(i) + ": triangle rows past the triangle array");
-                        uint32_t prim;
-                        memcpy(&prim, tris + (row + 2) * 4 + 3, 4);
-                        if ((uint64_t)off[2] + prim >= attrCount) return bad("instance " + std::to_string(i) + ": primitive index has no attribute record");
-                    }
-                }
-            }
+            const std::array<int32_t, 3> key = {off[0], off[1], off[2]};
+            bool done = false;
+            for (const auto& k : walked) if (k == key) { done = true; break; }
+            if (done) continue;
+            if (!walk_blas((uint64_t)off[0], (uint64_t)off[1], (uint64_t)off[2], "instance " + std::to_string(i))) return false;
+            walked.push_back(key);
         }
     }
     return true;
@@ -359,12 +403,14 @@ int render_to(PTContext* c, const PTFrameParams* hostParams, float4* dOut, const
         const uint32_t bounces = p->MaxRayBounces > 1u ? p->MaxRayBounces : 1u;
         if (spp > 4095u || bounces > 8191u) return fail(PT_ERR_UNSUPPORTED, "wavefront schedules pack SamplesPerPass <= 4095 and MaxRayBounces <= 8191");
         const uint64_t maxIt = (uint64_t)spp * (bounces + 2u) + 4u;
+        if (c->nextSet >= c->numSets) c->nextSet = 0u;
         PTContext::WfSet& set = c->sets[c->nextSet];
-        c->nextSet = (c->nextSet + 1u) % PT_WF_SETS;
-        // every set is carved on the FIRST pass of a frame size (a no-op afterwards): a caller that times passes after a short
-        // warm-up must not find the allocation of sets it has not reached yet inside its timed region
-        for (auto& other : c->sets)
-            if ((rc = ensure_wavefront(c, other, pt_num_slots(tm), (uint32_t)(maxIt > 65536u ? 65536u : maxIt)))) return rc;
+        c->nextSet = (c->nextSet + 1u) % c->numSets;
+        // every set IN USE is carved on the FIRST pass of a frame size (a no-op afterwards): a caller that times passes after a
+        // short warm-up must not find the allocation of sets it has not reached yet inside its timed region.  Sets beyond
+        // PTSetPassesInFlight are never allocated (0.6 GB each at 1080p).
+        for (uint32_t k = 0; k < c->numSets; ++k)
+            if ((rc = ensure_wavefront(c, c->sets[k], pt_num_slots(tm), (uint32_t)(maxIt > 65536u ? 65536u : maxIt)))) return rc;
         // the launch chain runs on the set's own stream; only its resolve (which reads `accumulated` and writes `output`)
         // is ordered after what the caller has enqueued on the context stream so far, the previous pass included
         HIP_TRY(hipEventRecord(set.callEv, c->stream));
@@ -411,6 +457,7 @@ PT_API int PTCreate(int deviceIndex, PTContext** outCtx)
     HIP_TRY(hipSetDevice(deviceIndex));
     PTContext* c = new PTContext();
     c->device = deviceIndex;
+    c->numSets = default_passes_in_flight();
     hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (se != hipSuccess) { delete c; return fail(PT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(se)); }
     se = hipMalloc((void**)&c->dStats, 16 * sizeof(unsigned long long));
@@ -442,7 +489,12 @@ PT_API int PTDestroy(PTContext* c)
     return PT_OK;
 }
 
-PT_API int PTSetScene(PTContext* c, const PTSceneDesc* hostScene)
+namespace { int set_scene(PTContext* c, const PTSceneDesc* hostScene, bool validate); }
+PT_API int PTSetScene(PTContext* c, const PTSceneDesc* hostScene) { return set_scene(c, hostScene, true); }
+
+} // extern "C"
+namespace {
+int set_scene(PTContext* c, const PTSceneDesc* hostScene, bool validate)
 {
     if (!c || !hostScene) return fail(PT_ERR_INVALID_ARG, "ctx/scene == NULL");
     if (hostScene->structSize < PT_SCENE_DESC_MIN_SIZE || hostScene->structSize > 4096u)
@@ -465,7 +517,7 @@ PT_API int PTSetScene(PTContext* c, const PTSceneDesc* hostScene)
     const bool envOn = (s->features & PT_FEATURE_HAS_ENVIRONMENT_TEXTURE) != 0;
     if (envOn && (!s->envTexture || s->envWidth == 0 || s->envHeight == 0 || (uint64_t)s->envWidth * s->envHeight > 0x7FFFFFFFull))
         return fail(PT_ERR_INVALID_ARG, "HAS_ENVIRONMENT_TEXTURE needs envTexture, envWidth, envHeight");
-    {
+    if (validate) {
         std::string why;
         if (!validate_scene(*s, why)) return fail(PT_ERR_INVALID_ARG, "scene refused: " + why);
     }
@@ -533,6 +585,8 @@ PT_API int PTSetScene(PTContext* c, const PTSceneDesc* hostScene)
     c->hasScene = true;
     return PT_OK;
 }
+} // namespace
+extern "C" {
 
 PT_API int PTSetTileOwnership(PTContext* c, int rank, int worldSize)
 {
@@ -788,6 +842,23 @@ PT_API int PTSetSchedule(PTContext* c, int schedule)
     return PT_OK;
 }
 
+PT_API int PTSetPassesInFlight(PTContext* c, int passes)
+{
+    if (!c || passes < 0 || passes > PT_WF_SETS) return fail(PT_ERR_INVALID_ARG, "ctx == NULL or passes outside 0.." + std::to_string(PT_WF_SETS));
+    HIP_TRY(hipSetDevice(c->device));
+    for (auto& set : c->sets) if (set.stream) HIP_TRY(hipStreamSynchronize(set.stream));
+    c->numSets = passes == 0 ? default_passes_in_flight() : (uint32_t)passes;
+    c->nextSet = 0u;
+    // sets that are no longer used give their memory back
+    for (uint32_t k = c->numSets; k < (uint32_t)PT_WF_SETS; ++k) {
+        PTContext::WfSet& set = c->sets[k];
+        if (set.arena) { hipFree(set.arena); set.arena = nullptr; set.arenaBytes = 0; set.wf = PTWfBuffers{}; }
+    }
+    return PT_OK;
+}
+
+PT_API int PTGetPassesInFlight(PTContext* c) { return c ? (int)c->numSets : fail(PT_ERR_INVALID_ARG, "ctx == NULL"); }
+
 PT_API int PTSetWavefrontIterations(PTContext* c, int iterations)
 {
     if (!c || iterations < 0) return fail(PT_ERR_INVALID_ARG, "ctx == NULL or iterations < 0");
@@ -838,6 +909,8 @@ struct PTGroup {
     std::vector<float4*> packed;        // on device i: its owned tiles, dense
     std::vector<float4*> staged;        // on the root device: the same, after the peer copy (staged[0] == packed[0])
     std::vector<hipEvent_t> arrived;    // recorded on ctx[i]->stream after the peer copy
+    std::vector<hipEvent_t> unpacked;   // recorded on the root's stream after staged[i] was scattered into the assembled frame
+    std::vector<char> unpackedValid;
     std::vector<size_t> packedBytes;
     float4* assembled = nullptr;
     uint32_t frameW = 0, frameH = 0;
@@ -921,7 +994,11 @@ PT_API int PTCreateMulti(const int* devices, int n, PTGroup** out)
     g->staged.assign(n, nullptr);
     g->packedBytes.assign(n, 0);
     g->arrived.assign(n, nullptr);
+    g->unpacked.assign(n, nullptr);
+    g->unpackedValid.assign(n, 0);
     for (int i = 0; i < n; ++i) {
+        hipSetDevice(g->ctx[0]->device);
+        if (hipEventCreateWithFlags(&g->unpacked[i], hipEventDisableTiming) != hipSuccess) { PTGroupDestroy(g); return fail(PT_ERR_HIP, "hipEventCreate failed"); }
         hipSetDevice(g->ctx[i]->device);
         if (hipEventCreateWithFlags(&g->arrived[i], hipEventDisableTiming) != hipSuccess) { PTGroupDestroy(g); return fail(PT_ERR_HIP, "hipEventCreate failed"); }
         // direct xGMI copies into the root's staging buffers; "already enabled" / "not supported" leave the staged path
@@ -941,6 +1018,7 @@ PT_API int PTGroupDestroy(PTGroup* g)
         if (g->packed[i]) hipFree(g->packed[i]);
         if (i > 0 && g->staged[i]) { hipSetDevice(g->ctx[0]->device); hipFree(g->staged[i]); }
         if (g->arrived[i]) hipEventDestroy(g->arrived[i]);
+        if (g->unpacked[i]) hipEventDestroy(g->unpacked[i]);
     }
     if (g->assembled) { hipSetDevice(g->ctx[0]->device); hipStreamSynchronize(g->ctx[0]->stream); hipFree(g->assembled); }
     for (PTContext* c : g->ctx) PTDestroy(c);
@@ -954,7 +1032,10 @@ PT_API PTContext* PTGroupGetContext(PTGroup* g, int i) { return (g && i >= 0 && 
 PT_API int PTGroupSetScene(PTGroup* g, const PTSceneDesc* scene)
 {
     if (!g) return fail(PT_ERR_INVALID_ARG, "group == NULL");
-    return for_each_device(g, [&](int i) { return PTSetScene(g->ctx[i], scene); });
+    // the index validation walks the whole scene on the host: once for the group, not once per device
+    int rc = set_scene(g->ctx[0], scene, true);
+    if (rc) return rc;
+    return for_each_device(g, [&](int i) { return i == 0 ? PT_OK : set_scene(g->ctx[i], scene, false); });
 }
 
 PT_API int PTGroupRenderPass(PTGroup* g, const PTFrameParams* hostParams)
@@ -970,6 +1051,9 @@ PT_API int PTGroupRenderPass(PTGroup* g, const PTFrameParams* hostParams)
         PTContext* c = g->ctx[i];
         int r = PTRenderPass(c, &p);                                   // owned tiles into the device's own ping-pong frames
         if (r) return r;
+        // staged[i] (and packed[0], which the root unpacks in place) may only be overwritten once the root has scattered the
+        // previous pass's tiles out of it: a straggling root must not see tiles of pass k+1 in the assembled frame of pass k
+        if (g->unpackedValid[i]) HIP_TRY(hipStreamWaitEvent(c->stream, g->unpacked[i], 0));
         HIP_TRY(pt_launch_pack_tiles(pt_make_tile_map(p, i, world), p.OutputWidth, c->frames[c->cur], g->packed[i], c->stream));
         if (i > 0) HIP_TRY(hipMemcpyPeerAsync(g->staged[i], root->device, g->packed[i], c->device, g->packedBytes[i], c->stream));
         HIP_TRY(hipEventRecord(g->arrived[i], c->stream));
@@ -980,6 +1064,8 @@ PT_API int PTGroupRenderPass(PTGroup* g, const PTFrameParams* hostParams)
     for (int i = 0; i < world; ++i) {
         if (i > 0) HIP_TRY(hipStreamWaitEvent(root->stream, g->arrived[i], 0));
         HIP_TRY(pt_launch_unpack_tiles(pt_make_tile_map(p, i, world), p.OutputWidth, g->staged[i], g->assembled, root->stream));
+        HIP_TRY(hipEventRecord(g->unpacked[i], root->stream));
+        g->unpackedValid[i] = 1;
     }
     return PT_OK;
 }

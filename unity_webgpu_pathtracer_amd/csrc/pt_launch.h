@@ -81,9 +81,9 @@ struct PTWfBuffers {
     float4* f4base;
     uint32_t f4stride;          // in float4 elements
     uint8_t* occl;              // [2][numSlots] written by trace kinds 1, 2
-    uint2* stackSpill;          // [numSlots][32 - PT_WF_LDS_STACK]: traversal-stack entries beyond the LDS part (refill / persistent trace kernels)
+    uint2* stackSpill;          // [numSlots / 64 waves x 64 lanes][32 - PT_WF_LDS_STACK]: traversal-stack entries beyond the LDS part (refill / persistent trace kernels)
     uint32_t* tlasSpill;        // [numSlots][32]: HAS_TLAS refill kernel, TLAS-stack entries beyond its LDS part (allocated for HAS_TLAS scenes only)
-    uint4* susp;                // [numSlots / 64][PT_WF_SUSPEND_MAX][6]: suspended rays of the refill trace kernel (pt_wavefront.hip)
+    uint4* susp;                // [numSlots / 64][PT_WF_SUSPEND][6]: suspended rays of the refill trace kernel (pt_wavefront.hip)
     uint32_t* suspCount;        // [numSlots / 64]
     uint32_t* aliveFlags;       // [maxIterations]
     uint32_t* chunkHeads;       // [8 shards x 32 words]: work counters of the persistent trace kernel, one 128-B line each
@@ -92,11 +92,30 @@ struct PTWfBuffers {
     uint32_t residentWaves;     // waves the device holds at the trace kernel's occupancy (CUs x 4 SIMDs x 8)
 };
 
+// Refill trace launches: 128 slots per wave while that still gives a quarter of the device's wave slots a wave (1080p: 16,320
+// waves for 8,192 slots, +2.4 %; half and quarter frames: +2 %), 64 for smaller launches.  Shared by the launcher and by the
+// arena sizing of pt_api.hip (a trace wave addresses 64 slab rows and PT_WF_SUSPEND records).
+#ifndef PT_WF_WIDE_DIV
+#define PT_WF_WIDE_DIV 4u       // with 12 sets in flight: 1/4 of a 1080p frame 5.09 vs 5.21 ms, 1/8 equal either way
+#endif
+inline bool pt_wf_wide_ranges(uint32_t numSlots, uint32_t residentWaves) { return (numSlots / 128u) >= residentWaves / PT_WF_WIDE_DIV; }
+// most trace waves any schedule launches over a set of numSlots slots (refill: numSlots / 64 or / 128; persistent: <= residentWaves)
+inline uint32_t pt_wf_max_trace_waves(uint32_t numSlots, uint32_t residentWaves)
+{
+    const uint32_t narrow = (numSlots + 63u) / 64u;
+    if (!pt_wf_wide_ranges(numSlots, residentWaves)) return narrow;
+    const uint32_t wide = (numSlots + 127u) / 128u, persist = residentWaves < narrow ? residentWaves : narrow;
+    return wide > persist ? wide : persist;
+}
+
 hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const float4* accumulated, float4* output,
                                const PTTileMap& tm, const PTWfBuffers& B, unsigned long long* gstats, bool fullStats,
                                hipStream_t stream, hipEvent_t orderAfter, bool zeroOutputFirst,
                                uint32_t* launchesOut, int traceVariant, uint32_t iterationsOverride);
-#define PT_WF_SUSPEND_MAX 32u   // record slots per trace wave (PT_WF_SUSPEND <= this)
+#ifndef PT_WF_SUSPEND
+#define PT_WF_SUSPEND 16u       // refill trace kernel: a wave whose range is exhausted stops when this many rays or fewer are left, and leaves them
+                                // as records for the tail launch (pt_wavefront.hip); 0 = off.  Also the record slots per trace wave (pt_api.hip)
+#endif
 #ifndef PT_WF_SETS
 #define PT_WF_SETS 12            // path-state sets = passes that can be in flight at once, each on its own stream (3 -> 6 sets with 8 hardware queues: +12 %;
                                  // 6 -> 12 sets with 16 queues: +2 % at 1080p, +7 % at 960x540, -14 % time for a 1/8 share of a 1080p frame; 16: no better, 24: worse)

@@ -173,10 +173,6 @@ static_assert(PT_WF_RANGE >= 64u && (PT_WF_RANGE & (PT_WF_RANGE - 1u)) == 0u,
 #ifndef PT_WF_HIT_REGS
 #define PT_WF_HIT_REGS 1        // main refill launch (with PT_WF_TRI_PARK): the hit's (u, v, triIndex) stay in registers until the ray ends
 #endif
-#ifndef PT_WF_WIDE_DIV
-#define PT_WF_WIDE_DIV 4u       // 128-slot ranges while the launch still has residentWaves / PT_WF_WIDE_DIV waves (with 12 sets in flight:
-                                // 1/4 of a 1080p frame 5.09 vs 5.21 ms, 1/8 equal either way)
-#endif
 #if PT_WF_FLAT == 2
 #define PT_WF_STEP ray_unistep
 #else
@@ -228,9 +224,7 @@ PT_DEV bool ray_exists(uint32_t f, uint32_t kind)
 // TAIL launch of the same kernel packs the records of PT_WF_TAIL_GROUP consecutive waves into full waves and resumes
 // them.  A ray resumes exactly where it stopped, so results and counters are unchanged; late, sparse iterations (a
 // handful of rays per 64-slot range) become a cheap scan + an 8:1 compacted tail.
-#ifndef PT_WF_SUSPEND
-#define PT_WF_SUSPEND 16u       // 0 = off
-#endif
+// PT_WF_SUSPEND (pt_launch.h, default 16; 0 = off)
 #ifndef PT_WF_TAIL_GROUP
 #define PT_WF_TAIL_GROUP 8u     // source waves per tail wave
 #endif
@@ -1072,9 +1066,7 @@ hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const fl
             if (fullStats) hipLaunchKernelGGL(pt_wf_trace_persist<true>, dim3(waves), dim3(64), 0, stream, S, B);
             else hipLaunchKernelGGL(pt_wf_trace_persist<false>, dim3(waves), dim3(64), 0, stream, S, B);
         } else if (traceVariant == 2) {
-            // 128 slots per wave while that still gives a quarter of the wave slots of the device a wave (1080p: 16,320 waves for
-            // 8,192 slots, +2.4 %; half and quarter frames: +2 %); 64 for smaller launches
-            const bool wide = PT_WF_RANGE >= 128u && (B.numSlots / 128u) >= B.residentWaves / PT_WF_WIDE_DIV;
+            const bool wide = PT_WF_RANGE >= 128u && pt_wf_wide_ranges(B.numSlots, B.residentWaves);         // pt_launch.h
             const uint32_t blocks = wide ? (B.numSlots + 127u) / 128u : (B.numSlots + 63u) / 64u;
             if (wide) {
                 if (fullStats) hipLaunchKernelGGL((pt_wf_trace_refill<true, false, 128u>), dim3(blocks), dim3(64), 0, stream, S, B);

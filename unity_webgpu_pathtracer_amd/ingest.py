@@ -244,17 +244,29 @@ def _node_matrix(node):
     return m
 
 
-def load_glb(path, unity_handedness=True, load_images=True):
+def load_glb(path, unity_handedness=True, load_images=True, flip_axis=2, flip_v=False):
     """Reads a .glb into (meshes, materials, images):
       meshes     one `Mesh` per triangle primitive of every node of the default scene, local_to_world = the node's world matrix
       materials  one dict per glTF material: base_color (linear rgba), metallic, roughness, emissive, alpha_mode (0 opaque,
                  1 mask, 2 blend), alpha_cutoff, tex_base / tex_mr / tex_emission / tex_occlusion / tex_normal = image index or -1
       images     (h, w, 4) float32 arrays in [0, 1] (PNG / JPEG decoded with Pillow when it is installed, else None entries)
-    unity_handedness: glTF is right-handed, Unity left-handed; UnityGLTF negates z of positions / normals / tangents (and of the
-    node transforms) and reverses the winding, which is what BVHScene then sees.  Primitive modes other than TRIANGLES raise."""
+    unity_handedness: glTF is right-handed, Unity left-handed, so the importer mirrors ONE axis of positions / normals / tangents
+    (and of the node transforms) and reverses the winding; BVHScene then sees the mirrored meshes.
+    PARITY UNPINNED -- an assumption, not a fact about the reference: its importer is the package org.khronos.unitygltf 2.14.1
+    (Packages/manifest.json), whose source is not in the reference tree and cannot be run here.  `flip_axis` (0 = x, 1 = y,
+    2 = z) selects the mirrored axis: 2 is what early UnityGLTF releases did (CoordinateSpaceConversionScale (1, 1, -1)); later
+    2.x releases are believed to mirror x instead ((-1, 1, 1)), which differs from the z flip by a half turn about y -- the model
+    faces the other way for the same camera.  The same releases also negate tangent.w and flip the V texture coordinate
+    (v -> 1 - v, with images stored bottom row first); `flip_v` applies the latter, tangent.w is not carried at all (the hot path
+    reads no tangents: the normal-map code of util/material.hlsl:114-133 is commented out).  Neither choice changes what the
+    kernels compute for given buffers.  Primitive modes other than TRIANGLES raise."""
     with open(path, "rb") as f:
         doc, blob = _glb_chunks(f.read())
-    flip = np.diag([1.0, 1.0, -1.0, 1.0]) if unity_handedness else np.eye(4)
+    if flip_axis not in (0, 1, 2):
+        raise ValueError("flip_axis must be 0, 1 or 2")
+    mirror = np.ones(3, np.float32)
+    mirror[flip_axis] = -1.0
+    flip = np.diag([float(mirror[0]), float(mirror[1]), float(mirror[2]), 1.0]) if unity_handedness else np.eye(4)
     meshes = []
 
     def visit(index, parent):
@@ -273,14 +285,16 @@ def load_glb(path, unity_handedness=True, load_images=True):
                 if idx is not None and (idx.size % 3 or (idx.size and int(idx.max()) >= len(pos))):
                     raise ValueError("index accessor does not describe triangles of this primitive")
                 if unity_handedness:
-                    pos = pos * np.array([1, 1, -1], np.float32)
-                    nrm = nrm * np.array([1, 1, -1], np.float32) if nrm is not None else None
-                    tan = tan * np.array([1, 1, -1], np.float32) if tan is not None else None
+                    pos = pos * mirror
+                    nrm = nrm * mirror if nrm is not None else None
+                    tan = tan * mirror if tan is not None else None
                     if idx is not None:
                         idx = idx.reshape(-1, 3)[:, ::-1].reshape(-1)
                     else:
                         order = np.arange(len(pos)).reshape(-1, 3)[:, ::-1].reshape(-1)
                         pos, nrm, tan, uv = pos[order], (nrm[order] if nrm is not None else None), (tan[order] if tan is not None else None), (uv[order] if uv is not None else None)
+                if flip_v and uv is not None:
+                    uv = uv * np.array([1, -1], np.float32) + np.array([0, 1], np.float32)
                 if idx is not None:
                     idx = idx.astype(np.uint16 if len(pos) < 65536 else np.uint32)
                 meshes.append(Mesh(positions=np.ascontiguousarray(pos), normals=nrm, tangents=tan, uvs=uv, indices=idx,

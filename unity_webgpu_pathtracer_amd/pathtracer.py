@@ -258,6 +258,13 @@ class PathTracer:
     def set_wavefront_iterations(self, n: int):
         plugin.check(self.lib.PTSetWavefrontIterations(self.ctx, n))
 
+    def set_passes_in_flight(self, n: int):
+        """0 = default for the hardware queues the process asked for (GPU_MAX_HW_QUEUES); 1 = passes back to back."""
+        plugin.check(self.lib.PTSetPassesInFlight(self.ctx, n))
+
+    def passes_in_flight(self) -> int:
+        return self.lib.PTGetPassesInFlight(self.ctx)
+
     def close(self):
         if self.ctx:
             self.lib.PTDestroy(self.ctx)
