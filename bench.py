@@ -151,7 +151,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=8)
     ap.add_argument("--bounces", type=int, default=4)
-    ap.add_argument("--schedule", type=int, default=-1, help="-1 auto (default: wavefront, megakernel for <=16-node scenes), 0 megakernel, 1 wavefront, 2/3 variants")
+    ap.add_argument("--schedule", type=int, default=-1, help="-1 auto, 0 megakernel, 1 wavefront (refill trace + shade launches), 2/3 variants, 4 fused persistent wavefront")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL (default); gloo only to rehearse N>1 on a one-GPU box")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--force-dist", action="store_true", help="rehearsal: run the N>1 code path (process group, per-frame reduce) even with one rank")
@@ -368,7 +368,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": {0: "pt_megakernel", 1: "pt_wf_trace_refill (main + tail) + pt_wf_shade (whole pass)", 2: "pt_wf_trace + pt_wf_shade (whole pass)",
-                                    3: "pt_wf_trace_persist + pt_wf_shade (whole pass)"}[main_res["schedule"]],
+                                    3: "pt_wf_trace_persist + pt_wf_shade (whole pass)", 4: "pt_wf_fused (one persistent launch per pass)"}[main_res["schedule"]],
                          "kernel_ms": round(main_res["kernel_ms"], 4), "pass_span_ms": round(main_res["pass_span_ms"], 4),
                          "algorithmic_bytes_per_launch": round(main_res["alg_bytes_per_launch"]),
                          "counters_per_launch": {k: round(v) for k, v in main_res["counters_per_launch"].items()},

@@ -42,7 +42,7 @@ ALL_COUNTERS = ["paths", "closestHitRays", "shadowRays", "nodeVisits", "triTests
                 "stackOverflows", "tlasNodeVisits", "instanceVisits"]
 
 
-SCHEDULES = [0, 1, 2, 3]    # 0 megakernel, 1 wavefront + refill trace, 2 wavefront one ray per lane, 3 wavefront + persistent dynamic-chunk trace
+SCHEDULES = [0, 1, 2, 3, 4]    # 4 fused persistent wavefront; 0 megakernel, 1 wavefront + refill trace, 2 wavefront one ray per lane, 3 wavefront + persistent dynamic-chunk trace
 
 
 @pytest.mark.parametrize("schedule", SCHEDULES)

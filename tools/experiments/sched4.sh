@@ -1,0 +1,9 @@
+#!/bin/bash
+# schedule 4 (fused persistent wavefront) against schedule 1, throughput and latency legs
+for cfg in "1 0" "4 1" "4 2" "4 3"; do
+  set -- $cfg
+  python bench.py --schedule $1 --passes-in-flight $2 --no-extra --no-cpu-baseline --no-alg-replay 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('schedule $1 passes_in_flight', d['config']['passes_in_flight'], ': %.0f Mrays/s  %.2f ms/pass  latency %.2f ms (%s)  crc %d' % (d['value'], d['ms_per_step'], d['latency_mode']['ms_per_pass'], d['latency_mode']['ms_per_pass_all'], d['config']['frame_crc32']))"
+done

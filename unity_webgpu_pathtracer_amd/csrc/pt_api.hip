@@ -165,7 +165,7 @@ int ensure_wavefront(PTContext* c, PTContext::WfSet& set, uint32_t numSlots, uin
     const size_t spillBytes = traceWaves * 64u * (size_t)(PT_BVH_STACK_SIZE - PT_WF_LDS_STACK) * sizeof(uint2);
     const size_t suspBytes = traceWaves * (size_t)(PT_WF_SUSPEND ? PT_WF_SUSPEND : 1u) * 6 * sizeof(uint4);
     const size_t tlasSpillBytes = needTlas ? traceWaves * 64u * (size_t)PT_BVH_STACK_SIZE * sizeof(uint32_t) : 0;
-    size_t total = align(n * 4) * 2 + align(n * 16) * 13 + align(n * 2) + align((size_t)maxIterations * 4) +
+    size_t total = align(n * 4) * 2 + align(n * 16) * PT_F4_COUNT + align(n * 2) + align((size_t)maxIterations * 4) +
                    align((size_t)numRows * 16 * 8) + align(8 * 32 * 4) + align(spillBytes) + align(suspBytes) + align(traceWaves * 4) + align(tlasSpillBytes);
     if (set.arena && set.arenaBytes < total) { hipFree(set.arena); set.arena = nullptr; set.arenaBytes = 0; }
     if (!set.arena) {
@@ -177,7 +177,7 @@ int ensure_wavefront(PTContext* c, PTContext::WfSet& set, uint32_t numSlots, uin
     PTWfBuffers& B = set.wf;
     B.flags = (uint32_t*)carve(n * 4);
     B.rng = (uint32_t*)carve(n * 4);
-    float4** arrs[PT_F4_COUNT] = {&B.ro, &B.rd, &B.rad, &B.thr, &B.color, &B.neeO, &B.envD, &B.lightD, &B.envC, &B.lightC, &B.pthr, &B.hit, &B.hit2};   // PT_F4_* order
+    float4** arrs[PT_F4_COUNT] = {&B.ro, &B.rd, &B.rad, &B.thr, &B.color, &B.neeO, &B.envD, &B.lightD, &B.envC, &B.lightC, &B.pthr, &B.hit, &B.hit2, &B.pixsum};   // PT_F4_* order
     for (auto a : arrs) *a = (float4*)carve(n * 16);
     B.f4base = B.ro;
     B.f4stride = (uint32_t)(align(n * 16) / 16);
@@ -398,7 +398,8 @@ int render_to(PTContext* c, const PTFrameParams* hostParams, float4* dOut, const
     switch (schedule) {
     case 1:
     case 2:
-    case 3: {
+    case 3:
+    case 4: {
         const uint32_t spp = p->SamplesPerPass > 1 ? (uint32_t)p->SamplesPerPass : 1u;
         const uint32_t bounces = p->MaxRayBounces > 1u ? p->MaxRayBounces : 1u;
         if (spp > 4095u || bounces > 8191u) return fail(PT_ERR_UNSUPPORTED, "wavefront schedules pack SamplesPerPass <= 4095 and MaxRayBounces <= 8191");
@@ -416,7 +417,7 @@ int render_to(PTContext* c, const PTFrameParams* hostParams, float4* dOut, const
         HIP_TRY(hipEventRecord(set.callEv, c->stream));
         if (c->profiling) HIP_TRY(hipEventRecord(ep.start, set.stream));
         HIP_TRY(pt_launch_wavefront(c->scene, *p, dAcc, dOut, tm, set.wf, c->dStats, c->statsLevel > 0, set.stream, set.callEv,
-                                    c->world > 1, &launches, schedule == 1 ? 2 : (schedule == 2 ? 1 : 0), c->wfIterations));
+                                    c->world > 1, &launches, schedule == 4 ? 4 : (schedule == 1 ? 2 : (schedule == 2 ? 1 : 0)), c->wfIterations));
         if (c->profiling) HIP_TRY(hipEventRecord(ep.stop, set.stream));
         HIP_TRY(hipEventRecord(set.done, set.stream));
         HIP_TRY(hipStreamWaitEvent(c->stream, set.done, 0));          // consumers of the context stream see the finished frame
@@ -836,8 +837,8 @@ PT_API int PTGetSchedule(PTContext* c)
 PT_API int PTSetSchedule(PTContext* c, int schedule)
 {
     if (!c) return fail(PT_ERR_INVALID_ARG, "ctx == NULL");
-    if (schedule < -1 || schedule > 3)
-        return fail(PT_ERR_UNSUPPORTED, "unknown schedule (0 = megakernel, 1 = wavefront + refill trace, 2 = wavefront, one ray per lane, 3 = wavefront + persistent dynamic-chunk trace)");
+    if (schedule < -1 || schedule > 4)
+        return fail(PT_ERR_UNSUPPORTED, "unknown schedule (0 = megakernel, 1 = wavefront + refill trace, 2 = wavefront, one ray per lane, 3 = wavefront + persistent dynamic-chunk trace, 4 = fused persistent wavefront)");
     c->schedule = schedule;
     return PT_OK;
 }

@@ -62,7 +62,7 @@ hipError_t pt_launch_present(const PTPresentParams& Q, const float4* src, float4
 
 // ---- schedule 1 (wavefront): slot-indexed path state in HBM (see pt_wavefront.hip) ----
 enum : uint32_t { PT_F4_RO = 0, PT_F4_RD, PT_F4_RAD, PT_F4_THR, PT_F4_COLOR, PT_F4_NEEO, PT_F4_ENVD, PT_F4_LIGHTD, PT_F4_ENVC, PT_F4_LIGHTC,
-                  PT_F4_PTHR, PT_F4_HIT, PT_F4_HIT2, PT_F4_COUNT };
+                  PT_F4_PTHR, PT_F4_HIT, PT_F4_HIT2, PT_F4_PIXSUM, PT_F4_COUNT };
 #ifndef PT_WF_LDS_STACK
 #define PT_WF_LDS_STACK 8       // traversal-stack entries per lane kept in LDS by the refill / persistent trace kernels; deeper ones go to stackSpill
 #endif
@@ -75,6 +75,7 @@ struct PTWfBuffers {
     float4 *envC, *lightC, *pthr;        // their contributions and the throughput they apply to
     float4* hit;                // [numSlots] (t, u, v, triIndex bits) written by trace kind 0
     float4* hit2;               // [numSlots] HAS_TLAS only: (world hit position, instance index bits)
+    float4* pixsum;             // [numSlots] schedule 4 only: a finished pixel's sample sum, indexed by PIXEL slot (the other arrays by context)
     // The thirteen float4 arrays above are carved back to back at a fixed stride: array k starts at f4base + k * f4stride
     // (order: PT_F4_*).  The trace kernels address them this way -- one base pointer instead of seven -- because at 8 waves/SIMD a
     // wave may hold 80 SGPRs, and every pointer costs two.
@@ -112,6 +113,9 @@ hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const fl
                                const PTTileMap& tm, const PTWfBuffers& B, unsigned long long* gstats, bool fullStats,
                                hipStream_t stream, hipEvent_t orderAfter, bool zeroOutputFirst,
                                uint32_t* launchesOut, int traceVariant, uint32_t iterationsOverride);
+#ifndef PT_WF_FUSED_GROUPS
+#define PT_WF_FUSED_GROUPS 4u   // schedule 4: groups of 64 path contexts a persistent wave owns (power of two; numSlots is a multiple of 256)
+#endif
 #ifndef PT_WF_SUSPEND
 #define PT_WF_SUSPEND 16u       // refill trace kernel: a wave whose range is exhausted stops when this many rays or fewer are left, and leaves them
                                 // as records for the tail launch (pt_wavefront.hip); 0 = off.  Also the record slots per trace wave (pt_api.hip)

@@ -832,12 +832,15 @@ PT_DEV void load_path(const PTWfBuffers& B, uint32_t slot, uint32_t f, PathRegs&
 // NEE terms, the two occlusion bytes, the hit record): requested where they are used they formed a chain of four dependent
 // round trips (state -> pending terms -> occlusion bytes -> hit record, ~870 cycles each at the shade kernel's 4 waves/SIMD)
 // in front of the attribute / material / texture chain.  A value the flags do not cover is read and ignored.
-template <bool STATS>
-PT_DEV bool shade_slot(const DScene& S, const PTFrameParams& P, const PTTileMap& tm, const PTWfBuffers& B, uint32_t slot, uint32_t f,
-                       Counters& cn)
+// `slot` indexes the path-state arrays; `pixelSlot` is the pixel the state belongs to (the same number in schedules 1-3, where
+// every pixel has its own slot; a context's current pixel in schedule 4, which also wants the finished pixel's sample sum in
+// B.pixsum[pixelSlot]: PIXSUM).
+template <bool STATS, bool PIXSUM = false>
+PT_DEV bool shade_slot(const DScene& S, const PTFrameParams& P, const PTTileMap& tm, const PTWfBuffers& B, uint32_t slot, uint32_t pixelSlot,
+                       uint32_t f, Counters& cn)
 {
     uint32_t px, py;
-    pt_slot_to_pixel(tm, slot, px, py);
+    pt_slot_to_pixel(tm, pixelSlot, px, py);
     uint32_t rng = B.rng[slot];
     float4 qro = B.ro[slot], qrd = B.rd[slot], qrad = B.rad[slot], qthr = B.thr[slot], qcol = B.color[slot];
     float4 qenvC = B.envC[slot], qlightC = B.lightC[slot], qpthr = B.pthr[slot], qhit = B.hit[slot];
@@ -893,6 +896,11 @@ PT_DEV bool shade_slot(const DScene& S, const PTFrameParams& P, const PTTileMap&
     uint32_t storeSlot = slot;
     asm volatile("" : "+v"(storeSlot));
     store_path(B, storeSlot, r, false);                             // the NEE arrays were written by the sink
+    if (PIXSUM && r.state == PS_DONE) {
+        uint32_t ps = pixelSlot;
+        asm volatile("" : "+v"(ps));
+        B.pixsum[ps] = f4(r.color, 0.0f);
+    }
     return r.state != PS_DONE;
 }
 
@@ -917,9 +925,297 @@ __global__ __launch_bounds__(PT_WF_SHADE_BLOCK, PT_WF_SHADE_MIN_WAVES) void pt_w
     if (__any(fl_state(f) != PS_DONE) && (threadIdx.x & 63u) == 0u) cn.tlasNodeVisits++;
     if (fl_state(f) != PS_DONE) cn.instanceVisits++;
 #endif
-    if (fl_state(f) != PS_DONE) alive = shade_slot<STATS>(S, P, tm, B, slot, f, cn);
+    if (fl_state(f) != PS_DONE) alive = shade_slot<STATS>(S, P, tm, B, slot, slot, f, cn);
     if (__any(alive) && (threadIdx.x & 63u) == 0u) B.aliveFlags[iteration] = 1u;     // diagnostics: last iteration anybody needed
     flush_counters<STATS>(cn, B.statRows, vb * (PT_WF_SHADE_BLOCK / 64u) + (threadIdx.x >> 6), threadIdx.x & 63u);
+}
+
+// ------------------------------------------------------------------------------------------
+// Schedule 4: the FUSED PERSISTENT wavefront.  One launch per pass; no launch boundary anywhere inside it.
+//
+// Paths of different pixels never exchange anything (PathTracer.compute:60), so nothing in a pass needs a grid-wide barrier: the
+// 52 x 3 launches of schedule 1 only exist because a launch is the unit in which that schedule alternates between the lean trace
+// code and the register-hungry shading code.  Here a persistent wave does the alternating itself, over path CONTEXTS it owns:
+//
+//     a wave owns PT_WF_FUSED_GROUPS x 64 contexts (path state in HBM, indexed by context, not by pixel);
+//     loop {  refill:  every context whose pixel has finished takes the next pixel of the frame from a device counter
+//                      (one atomic per wave and round; the camera ray of its first sample is written);
+//             trace:   the refill scheduler of pt_wf_trace_refill over the contexts' 3 x 64 x GROUPS candidate rays -- 64 resumable
+//                      traversals in flight, idle lanes re-filled by ballot / rank compaction -- until the candidates are used up
+//                      and <= PT_WF_SUSPEND rays are left; those are parked as records in LDS and resumed in the next round;
+//             shade:   path_step() for every context whose rays have all returned; a pixel that finished its last sample
+//                      leaves its sample sum in the per-pixel array the resolve kernel reads.  }
+//
+// Every context is busy until the frame runs out of pixels: there is no per-launch ramp-up and drain, no tail launch, no cleanup
+// kernel, and ONE pass in flight fills the machine -- a host that synchronises after every pass (the reference presents every
+// pass, PathTracer.cs:251-272) gets the pipelined throughput, with one path-state set of ~1 M contexts instead of twelve sets
+// of one slot per pixel.  A wave only ever touches the state of its own contexts, so ordering is program order within the
+// wave (workgroup-scope fences between phases).  Which context renders which pixel depends on timing; what is computed for a
+// pixel does not: same device functions, same per-path order as every other schedule -> frames and counters are bit-identical.
+// ------------------------------------------------------------------------------------------
+#ifndef PT_WF_FUSED_WAVES
+#define PT_WF_FUSED_WAVES 4         // waves per SIMD the fused kernel is compiled for (128 VGPRs)
+#endif
+#define PT_WF_NO_PIXEL 0xFFFFFFFFu
+
+// add a phase's counters to the wave's LDS totals (one wave per workgroup; 16 words, PTStats order)
+template <bool STATS>
+PT_DEV void counters_to_lds(const Counters& cn, volatile uint32_t* tot, uint32_t lane)
+{
+    uint32_t vals[PT_NUM_COUNTERS];
+    counters_to_array(cn, vals);
+#pragma unroll
+    for (int i = 0; i < PT_NUM_COUNTERS; ++i) {
+        if (!STATS && (i >= 3 && i <= 9)) continue;
+        if (!STATS && i >= 12) continue;
+        if (i == 12) {
+            const uint32_t m = wave_max_u32(vals[i]);
+            if (lane == 0u && m > tot[i]) tot[i] = m;
+        } else {
+            const uint32_t v = wave_sum_u32(vals[i]);
+            if (lane == 0u && v) tot[i] += v;
+        }
+    }
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(64, PT_WF_FUSED_WAVES) void pt_wf_fused(DScene S, PTFrameParams P, PTTileMap tm, PTWfBuffers B)
+{
+    constexpr uint32_t K = PT_WF_FUSED_GROUPS;
+    constexpr uint32_t kSusp = PT_WF_SUSPEND ? PT_WF_SUSPEND : 1u;
+    static_assert((K & (K - 1u)) == 0u && K >= 1u && K <= 16u, "context groups per wave: a power of two");
+    __shared__ uint2 s_stack[PT_WF_LDS_STACK][64];
+    __shared__ uint32_t s_xchg[64];
+    __shared__ uint32_t s_pix[K][64];           // the pixel (slot of the frame's enumeration, pt_slot_to_pixel) a context renders, or PT_WF_NO_PIXEL
+    __shared__ uint32_t s_pend[2][K][2];        // [buffer][group][low / high word]: contexts that have a ray parked in s_susp
+    __shared__ uint4 s_susp[kSusp][PT_WF_SUSP_ROWS];
+    __shared__ uint32_t s_cnt[PT_NUM_COUNTERS];
+    __shared__ uint32_t s_gw;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t ctxBase = blockIdx.x * (K * 64u);                 // context = ctxBase + group * 64 + lane
+    volatile uint32_t* xchg = s_xchg;
+    volatile uint32_t* pix = &s_pix[0][0];
+    volatile uint32_t* cnt = s_cnt;
+#pragma unroll
+    for (uint32_t k = 0; k < K; ++k) {
+        s_pix[k][lane] = PT_WF_NO_PIXEL;
+        B.flags[ctxBase + k * 64u + lane] = PS_DONE;                 // a context without a pixel has no rays (the trace scan reads the flag words)
+    }
+    if (lane < PT_NUM_COUNTERS) s_cnt[lane] = 0u;
+    if (lane < 4u * K) (&s_pend[0][0][0])[lane] = 0u;
+    if (lane == 0u) s_gw = blockIdx.x;
+    __builtin_amdgcn_wave_barrier();
+    uint32_t nSusp = 0u, pb = 0u;
+    bool more = true;
+
+    while (true) {
+        // ---- (0) refill: a context without a pixel takes the next pixel of the frame and starts its first sample
+        bool any = false;
+#pragma unroll 1
+        for (uint32_t k = 0; k < K; ++k) {
+            const uint32_t ctx = ctxBase + k * 64u + lane;
+            uint32_t mine = pix[k * 64u + lane];
+            const unsigned long long E = __ballot(mine == PT_WF_NO_PIXEL);
+            if (more && E != 0ull) {                                 // wave-uniform
+                const uint32_t n = (uint32_t)__popcll(E);
+                uint32_t base = 0u;
+                if (lane == 0u) base = atomicAdd(&B.chunkHeads[0], n);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (base + n >= B.numSlots) more = false;
+                Counters cn = {};
+                if (mine == PT_WF_NO_PIXEL) {
+                    const uint32_t slot = base + rank_below(E);
+                    uint32_t px, py;
+                    if (slot < B.numSlots && pt_slot_to_pixel(tm, slot, px, py)) {      // (slots of partially covered edge tiles have no pixel)
+                        PathRegs r;
+                        path_init(P, px, py, py * P.OutputWidth + px, r, cn);
+                        store_path(B, ctx, r, false);
+                        mine = slot;
+                        pix[k * 64u + lane] = slot;
+                    }
+                }
+                counters_to_lds<false>(cn, cnt, lane);
+            }
+            any = any || __ballot(mine != PT_WF_NO_PIXEL) != 0ull;
+        }
+        if (!any) { if (!more) break; else continue; }              // nothing to do: out of pixels -> done; else an edge tile gave none, pull again
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- (1) trace: resume what was parked, then scan the contexts' flag words kind-major and keep 64 traversals in flight
+        {
+            Counters cn = {};
+            TravStackT<PT_WF_LDS_STACK, true> st;
+            st.lds = &s_stack[0][lane];
+            st.stride = 64u;
+            st.gbase = B.stackSpill;
+            st.gwave = PT_LDS_WORD(s_gw);
+            RayState rs;
+            rs.sp = 0u; rs.anyHit = false; rs.overflow = false;
+            rs.o = mk3(0.0f); rs.d = mk3(0.0f); rs.invDir = mk3(0.0f); rs.octinv4 = 0u;
+            rs.ng = make_uint2(0u, 0u); rs.tg = make_uint2(0u, 0u);
+            rs.hit.t = PT_FAR_PLANE; rs.hit.u = 0.0f; rs.hit.v = 0.0f; rs.hit.triIndex = 0u;
+            bool have = false;
+            uint32_t myRef = 0u;                                     // kind << 30 | context index within the wave (group * 64 + lane)
+            const uint32_t po = pb, pn = pb ^ 1u;                    // pend masks: previous round (read), this round (written)
+            if (lane < 2u * K) (&s_pend[pn][0][0])[lane] = 0u;
+            // parked rays first: lane i takes record i (all lanes are idle here)
+            if (PT_WF_SUSPEND > 0u && lane < nSusp) {
+                const uint4 a = s_susp[lane][0], b = s_susp[lane][1];
+                myRef = a.x;
+                const uint32_t kind = myRef >> 30;
+                const uint32_t ctx = ctxBase + (myRef & 0x3FFFFFFFu);
+                v3 o, d;
+                fetch_ray(B, ctx, kind, o, d);
+                ray_begin(rs, o, d, kind != 0u);                     // same invDir / octinv4 as when the ray started
+                rs.sp = a.y & 0xFFu;
+                rs.overflow = (a.y & 0x100u) != 0u;
+                rs.ng = make_uint2(a.z, a.w);
+                rs.tg = make_uint2(b.x, b.y);
+                rs.hit.t = pt_asfloat(b.z);
+                if (kind == 0u && rs.hit.t < PT_FAR_PLANE) {         // the best hit so far was left in the hit array
+                    const float4 h = f4_array(B, PT_F4_HIT)[ctx];
+                    rs.hit.u = h.y; rs.hit.v = h.z; rs.hit.triIndex = pt_asuint(h.w);
+                }
+#pragma unroll
+                for (uint32_t e = 0; e < PT_WF_SUSP_STACK_ROWS; ++e) {
+                    const uint4 er = s_susp[lane][2u + e];
+                    st.lds[(2u * e) * 64u] = make_uint2(er.x, er.y);
+                    if (2u * e + 1u < PT_WF_LDS_STACK) st.lds[(2u * e + 1u) * 64u] = make_uint2(er.z, er.w);
+                }
+                have = true;
+            }
+            nSusp = 0u;
+            const uint32_t nItems = 3u * 64u * K;
+            uint32_t cursor = 0u;
+            bool startedNew = false;
+
+            auto finish = [&]() {                                    // the lane's ray is complete: write its result
+                const uint32_t kind = myRef >> 30;
+                const uint32_t ctx = ctxBase + (myRef & 0x3FFFFFFFu);
+                if (kind == 0u) {
+                    if (!(rs.hit.t < PT_FAR_PLANE)) store_miss(B, ctx);
+                    else f4_array(B, PT_F4_HIT)[ctx] = make_float4(rs.hit.t, rs.hit.u, rs.hit.v, pt_asfloat(rs.hit.triIndex));
+                } else store_occlusion(B, kind, ctx, rs.hit.t < PT_FAR_PLANE);
+                have = false;
+            };
+
+            while (true) {
+                uint32_t nIdle = (uint32_t)__popcll(__ballot(!have));
+                while (cursor < nItems && (nIdle >= PT_WF_REFILL || nIdle == 64u)) {
+                    const unsigned long long idle = __ballot(!have);
+                    const uint32_t rankI = rank_below(idle);
+                    const uint32_t item = cursor + lane;
+                    const uint32_t kind = item / (64u * K);
+                    const uint32_t local = item & (64u * K - 1u);    // group * 64 + lane of the context
+                    bool valid = item < nItems;
+                    if (valid) {
+                        const uint32_t pw = s_pend[po][local >> 6][(local >> 5) & 1u];
+                        // (a context with a parked ray got all its rays last round; one without a pixel is DONE)
+                        valid = !((pw >> (local & 31u)) & 1u) && ray_exists(B.flags[ctxBase + local], kind);
+                    }
+                    const unsigned long long V = __ballot(valid);
+                    const uint32_t nV = (uint32_t)__popcll(V);
+                    const uint32_t take = nIdle < nV ? nIdle : nV;
+                    const uint32_t rankV = rank_below(V);
+                    uint32_t consumed = 64u;
+                    if (take < nV) consumed = (uint32_t)__ffsll((long long)__ballot(valid && rankV == take)) - 1u;   // first ray NOT taken
+                    if (valid && rankV < take) xchg[rankV] = (kind << 30) | local;
+                    __builtin_amdgcn_wave_barrier();
+                    if (!have && rankI < take) {
+                        myRef = xchg[rankI];
+                        const uint32_t myKind = myRef >> 30;
+                        const uint32_t ctx = ctxBase + (myRef & 0x3FFFFFFFu);
+                        v3 o, d;
+                        fetch_ray(B, ctx, myKind, o, d);
+                        if (myKind == 0u) cn.closestRays++; else cn.shadowRays++;
+                        if (ray_begin(rs, o, d, myKind != 0u)) {
+                            if (myKind == 0u) store_miss(B, ctx);             // NaN ray: certain miss
+                            else store_occlusion(B, myKind, ctx, false);
+                        } else have = true;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (take > 0u) startedNew = true;
+                    cursor += consumed;
+                    nIdle = (uint32_t)__popcll(__ballot(!have));
+                }
+                if (nIdle == 64u) break;
+                const bool exhausted = cursor >= nItems;
+                // parking is allowed only in a round that started new rays: a round that merely resumed must finish them
+                const bool mayPark = PT_WF_SUSPEND > 0u && exhausted && startedNew;
+                const uint32_t stopAt = !exhausted ? PT_WF_REFILL : (mayPark ? 64u - PT_WF_SUSPEND : 64u);
+                while (nIdle < stopAt) {
+                    const bool wantTri = have && rs.tg.y != 0u;
+                    const uint32_t nT = (uint32_t)__popcll(__ballot(wantTri));
+                    const uint32_t nN = (uint32_t)__popcll(__ballot(have && !wantTri));
+                    bool fin = false;
+                    if ((nT >= PT_WF_TRI_PARK || nN == 0u) && wantTri) fin = ray_tri_one<STATS>(S, rs, cn);
+                    if (have && !fin && rs.tg.y == 0u) fin = ray_node_one<STATS>(S, rs, st, cn);
+                    if (fin) finish();
+                    nIdle = (uint32_t)__popcll(__ballot(!have));
+                }
+                if (mayPark && nIdle < 64u) {
+                    // a ray whose stack reaches into the HBM slab stays (a record only holds the LDS entries): finish those first
+                    while (__ballot(have && rs.sp > PT_WF_LDS_STACK) != 0ull) {
+                        if (have) {
+                            const bool fin = rs.tg.y != 0u ? ray_tri_one<STATS>(S, rs, cn) : ray_node_one<STATS>(S, rs, st, cn);
+                            if (fin) finish();
+                        }
+                    }
+                    const unsigned long long act = __ballot(have);
+                    if (have) {
+                        const uint32_t kind = myRef >> 30, local = myRef & 0x3FFFFFFFu;
+                        if (kind == 0u && rs.hit.t < PT_FAR_PLANE)
+                            f4_array(B, PT_F4_HIT)[ctxBase + local] = make_float4(rs.hit.t, rs.hit.u, rs.hit.v, pt_asfloat(rs.hit.triIndex));
+                        const uint32_t rec = rank_below(act);
+                        s_susp[rec][0] = make_uint4(myRef, rs.sp | (rs.overflow ? 0x100u : 0u), rs.ng.x, rs.ng.y);
+                        s_susp[rec][1] = make_uint4(rs.tg.x, rs.tg.y, pt_asuint(rs.hit.t), 0u);
+#pragma unroll
+                        for (uint32_t e = 0; e < PT_WF_SUSP_STACK_ROWS; ++e) {
+                            const uint2 x = st.lds[(2u * e) * 64u];
+                            const uint2 y = (2u * e + 1u < PT_WF_LDS_STACK) ? st.lds[(2u * e + 1u) * 64u] : make_uint2(0u, 0u);
+                            s_susp[rec][2u + e] = make_uint4(x.x, x.y, y.x, y.y);
+                        }
+                        atomicOr(&s_pend[pn][local >> 6][(local >> 5) & 1u], 1u << (local & 31u));
+                        have = false;
+                    }
+                    nSusp = (uint32_t)__popcll(act);
+                    break;
+                }
+            }
+            pb = pn;
+            counters_to_lds<STATS>(cn, cnt, lane);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- (2) shade: every context whose rays have all returned
+#pragma unroll 1
+        for (uint32_t k = 0; k < K; ++k) {
+            const uint32_t ctx = ctxBase + k * 64u + lane;
+            const uint32_t mine = pix[k * 64u + lane];
+            const uint32_t pw = s_pend[pb][k][lane >> 5];
+            const bool parked = (pw >> (lane & 31u)) & 1u;
+            Counters cn = {};
+            if (mine != PT_WF_NO_PIXEL && !parked) {
+                const uint32_t f = B.flags[ctx];
+                if (!shade_slot<STATS, true>(S, P, tm, B, ctx, mine, f, cn)) pix[k * 64u + lane] = PT_WF_NO_PIXEL;    // pixel finished: its sum is in B.pixsum
+            }
+            counters_to_lds<STATS>(cn, cnt, lane);                   // every lane of the wave takes part in the reductions
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // the wave's totals -> its counter row (a wave owns row blockIdx.x for the whole launch)
+    __builtin_amdgcn_wave_barrier();
+    if (lane < PT_NUM_COUNTERS) {
+        unsigned long long* p = B.statRows + (size_t)blockIdx.x * 16u + lane;
+        const unsigned long long v = cnt[lane];
+        if (lane == 12u) { if (v > *p) *p = v; } else if (v) *p += v;
+    }
 }
 
 // cleanup: pixels still alive after the fixed number of iterations are run to completion here, one lane per slot with
@@ -981,8 +1277,8 @@ __global__ __launch_bounds__(256, 2) void pt_wf_cleanup(DScene S, PTFrameParams 
 }
 
 // resolve: the pixel write of PathTracer.compute:89-98, applied to every slot's sample sum
-__global__ __launch_bounds__(256) void pt_wf_resolve(PTFrameParams P, PTTileMap tm, PTWfBuffers B, const float4* __restrict__ accumulated,
-                                                     float4* __restrict__ output)
+__global__ __launch_bounds__(256) void pt_wf_resolve(PTFrameParams P, PTTileMap tm, PTWfBuffers B, const float4* __restrict__ sums,
+                                                     const float4* __restrict__ accumulated, float4* __restrict__ output)
 {
     const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
     uint32_t px, py;
@@ -991,7 +1287,7 @@ __global__ __launch_bounds__(256) void pt_wf_resolve(PTFrameParams P, PTTileMap 
         const uint32_t pixelIndex = py * P.OutputWidth + px;
         const uint32_t numSamples = P.SamplesPerPass > 1 ? (uint32_t)P.SamplesPerPass : 1u;
         const float fSamples = (float)numSamples;
-        const v3 color = xyz(B.color[slot]);
+        const v3 color = xyz(sums[slot]);                       // per-pixel sample sum: B.color (schedules 1-3) or B.pixsum (schedule 4)
         v3 acc;
         if (P.CurrentSample > 0u) {
             float4 a = accumulated[pixelIndex];
@@ -1047,8 +1343,27 @@ hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const fl
     uint32_t launches = 0;
     hipError_t e;
     const bool tlas = S.hasTlas != 0u;
+    if (tlas && traceVariant == 4) traceVariant = 2;      // schedule 4 with HAS_TLAS: the two-level walk runs through schedule 1's refill kernel
     const bool tlasRefill = tlas && traceVariant == 2;    // schedule 1: two-level traversal through the refill scheduler
     if (tlas) traceVariant = 1;          // schedules 2, 3: the one-ray-per-lane trace kernel
+    if (traceVariant == 4 && !tlas) {
+        // schedule 4: one persistent launch renders the whole pass (pt_wf_fused); then the ordered pixel write and the counter fold
+        if ((e = hipMemsetAsync(B.chunkHeads, 0, sizeof(uint32_t), stream)) != hipSuccess) return e;
+        const uint32_t maxWaves = B.numSlots / (64u * PT_WF_FUSED_GROUPS);           // contexts never outnumber the frame's slots (array sizes)
+        uint32_t waves = B.residentWaves / 8u * (uint32_t)PT_WF_FUSED_WAVES;          // CUs x 4 SIMDs x waves per SIMD
+        if (waves > maxWaves) waves = maxWaves;
+        if (waves == 0u) waves = 1u;
+        if (fullStats) hipLaunchKernelGGL(pt_wf_fused<true>, dim3(waves), dim3(64), 0, stream, S, P, tm, B);
+        else hipLaunchKernelGGL(pt_wf_fused<false>, dim3(waves), dim3(64), 0, stream, S, P, tm, B);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if (orderAfter && (e = hipStreamWaitEvent(stream, orderAfter, 0)) != hipSuccess) return e;
+        if (zeroOutputFirst &&
+            (e = hipMemsetAsync(output, 0, (size_t)P.OutputWidth * P.OutputHeight * sizeof(float4), stream)) != hipSuccess) return e;
+        hipLaunchKernelGGL(pt_wf_resolve, dim3(nb), dim3(256), 0, stream, P, tm, B, (const float4*)B.pixsum, accumulated, output);
+        hipLaunchKernelGGL(pt_wf_fold_rows, dim3(256), dim3(256), 0, stream, B.statRows, B.numStatRows, gstats);
+        if (launchesOut) *launchesOut = 3u;
+        return hipGetLastError();
+    }
     if ((e = hipMemsetAsync(B.aliveFlags, 0, sizeof(uint32_t) * B.maxIterations, stream)) != hipSuccess) return e;
     hipLaunchKernelGGL(pt_wf_init, dim3(nb), dim3(256), 0, stream, P, tm, B);
     launches++;
@@ -1111,7 +1426,7 @@ hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const fl
     if (orderAfter && (e = hipStreamWaitEvent(stream, orderAfter, 0)) != hipSuccess) return e;
     if (zeroOutputFirst &&
         (e = hipMemsetAsync(output, 0, (size_t)P.OutputWidth * P.OutputHeight * sizeof(float4), stream)) != hipSuccess) return e;
-    hipLaunchKernelGGL(pt_wf_resolve, dim3(nb), dim3(256), 0, stream, P, tm, B, accumulated, output);
+    hipLaunchKernelGGL(pt_wf_resolve, dim3(nb), dim3(256), 0, stream, P, tm, B, (const float4*)B.color, accumulated, output);
     hipLaunchKernelGGL(pt_wf_fold_rows, dim3(256), dim3(256), 0, stream, B.statRows, B.numStatRows, gstats);
     launches += 3;
     if (launchesOut) *launchesOut = launches;
