@@ -316,9 +316,13 @@ PT_API int PTResetTimings(PTContext* ctx);
  *   0  megakernel: one lane per pixel, one launch per pass
  *   1  wavefront: slot-indexed path state, refill trace kernel + shade kernel, host-sync-free, passes overlap
  *   2  wavefront with the plain one-ray-per-lane trace kernel
- *   3  wavefront with the persistent dynamic-chunk trace kernel */
+ *   3  wavefront with the persistent dynamic-chunk trace kernel
+ *   4  fused persistent wavefront: ONE launch per pass; a persistent wave owns 128 path contexts, alternates between tracing
+ *      their rays and shading them, and hands a context whose pixel has finished the next pixel of the frame.  One path-state
+ *      set of ~0.5 M contexts instead of one slot per pixel and pass in flight; the fastest schedule when passes are NOT
+ *      pipelined (a host that presents every pass).  HAS_TLAS scenes run schedule 1's kernels. */
 PT_API int PTSetSchedule(PTContext* ctx, int schedule);
-/* The schedule (0..3) the next pass will run with the current scene: resolves -1 (auto).  Negative = error code. */
+/* The schedule (0..4) the next pass will run with the current scene: resolves -1 (auto).  Negative = error code. */
 PT_API int PTGetSchedule(PTContext* ctx);
 /* Wavefront schedules: number of trace+shade iterations launched per pass before the cleanup kernel finishes whatever is
  * still alive.  0 (default) = SamplesPerPass * (MaxRayBounces + 2) + 4.  Any value gives the same frame; it only moves

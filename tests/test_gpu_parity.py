@@ -196,7 +196,7 @@ def test_wavefront_cleanup_kernel_finishes_any_path(oracle, iterations):
     pt.close()
 
 
-@pytest.mark.parametrize("schedule", [0, 1])
+@pytest.mark.parametrize("schedule", [0, 1, 4])
 def test_pipelined_passes_without_host_sync(oracle, schedule):
     """Six progressive passes issued back to back (the wavefront schedule overlaps them on separate state sets and
     streams; only the resolves are ordered).  The final frame must equal six sequential oracle passes bit for bit."""

@@ -17,9 +17,10 @@ sys.path.insert(0, sys.argv[1])
 from unity_webgpu_pathtracer_amd import scenes
 from unity_webgpu_pathtracer_amd.pathtracer import PathTracer
 out = {}
-for name, s, w, h, spp in (("zoo", scenes.material_zoo(), 128, 80, 3), ("sponza", scenes.sponza_atrium(tex_size=8, detail=0.15), 128, 72, 2),
-                           ("tlas", scenes.instanced_scene(count=60, detail=8), 128, 72, 2)):
-    pt = PathTracer(s, width=w, height=h, samplesPerPass=spp, schedule=1)
+for name, s, w, h, spp, sched in (("zoo", scenes.material_zoo(), 128, 80, 3, 1), ("sponza", scenes.sponza_atrium(tex_size=8, detail=0.15), 128, 72, 2, 1),
+                                  ("tlas", scenes.instanced_scene(count=60, detail=8), 128, 72, 2, 1),
+                                  ("sponza_fused", scenes.sponza_atrium(tex_size=8, detail=0.15), 128, 72, 2, 4)):     # schedule 4: parked rays + slab
+    pt = PathTracer(s, width=w, height=h, samplesPerPass=spp, schedule=sched)
     pt.set_stats_level(1)
     pt.render_pass(pt.params(seed=0x57E55))
     out[name] = pt.readback()
@@ -40,7 +41,8 @@ def test_small_stack_build_is_bit_exact(tmp_path, oracle):
     from unity_webgpu_pathtracer_amd import scenes
     from unity_webgpu_pathtracer_amd.pathtracer import BVHScene
     for name, s, w, h, spp in (("zoo", scenes.material_zoo(), 128, 80, 3), ("sponza", scenes.sponza_atrium(tex_size=8, detail=0.15), 128, 72, 2),
-                               ("tlas", scenes.instanced_scene(count=60, detail=8), 128, 72, 2)):
+                               ("tlas", scenes.instanced_scene(count=60, detail=8), 128, 72, 2),
+                               ("sponza_fused", scenes.sponza_atrium(tex_size=8, detail=0.15), 128, 72, 2)):
         b = oracle.buffers_from_bvhscene(BVHScene(s))
         p = scenes.frame_params(s, w, h, spp=spp, seed=0x57E55)
         ref, st = oracle.render(b, p, shadow_any_hit=True)

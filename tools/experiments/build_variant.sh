@@ -18,5 +18,5 @@ for o in $(ls _obj/*.o | grep -v "/stress_"); do
   b=$(basename $o .o)
   if [ -f ../../tools/experiments/variants/_obj_$NAME/$b.o ]; then OBJS="$OBJS ../../tools/experiments/variants/_obj_$NAME/$b.o"; else OBJS="$OBJS $o"; fi
 done
-hipcc --offload-arch=gfx950 -shared -o ../../tools/experiments/variants/$NAME.so $OBJS -L/opt/rocm/lib -lrocprofiler-sdk-roctx 2>&1 | tail -3
+hipcc --offload-arch=gfx950 -shared -o ../../tools/experiments/variants/$NAME.so $OBJS -ldl 2>&1 | tail -3
 echo built tools/experiments/variants/$NAME.so

@@ -114,7 +114,8 @@ hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const fl
                                hipStream_t stream, hipEvent_t orderAfter, bool zeroOutputFirst,
                                uint32_t* launchesOut, int traceVariant, uint32_t iterationsOverride);
 #ifndef PT_WF_FUSED_GROUPS
-#define PT_WF_FUSED_GROUPS 4u   // schedule 4: groups of 64 path contexts a persistent wave owns (power of two; numSlots is a multiple of 256)
+#define PT_WF_FUSED_GROUPS 2u   // schedule 4: groups of 64 path contexts a persistent wave owns (power of two <= 4: numSlots is a multiple of 256).
+                                // Sponza-class 1080p / 8 spp, one pass in flight: 1: 29.9 ms, 2: 25.2, 4: 27.9, 8: 31.4
 #endif
 #ifndef PT_WF_SUSPEND
 #define PT_WF_SUSPEND 16u       // refill trace kernel: a wave whose range is exhausted stops when this many rays or fewer are left, and leaves them

@@ -956,6 +956,7 @@ __global__ __launch_bounds__(PT_WF_SHADE_BLOCK, PT_WF_SHADE_MIN_WAVES) void pt_w
 #ifndef PT_WF_FUSED_WAVES
 #define PT_WF_FUSED_WAVES 4         // waves per SIMD the fused kernel is compiled for (128 VGPRs)
 #endif
+
 #define PT_WF_NO_PIXEL 0xFFFFFFFFu
 
 // add a phase's counters to the wave's LDS totals (one wave per workgroup; 16 words, PTStats order)
@@ -1007,6 +1008,18 @@ __global__ __launch_bounds__(64, PT_WF_FUSED_WAVES) void pt_wf_fused(DScene S, P
     __builtin_amdgcn_wave_barrier();
     uint32_t nSusp = 0u, pb = 0u;
     bool more = true;
+#ifdef PT_FUSED_DIAG
+    // diagnostics build: wave time per phase (s_memtime ticks), rounds, reported through the shading counters of the FULL-stats variant:
+    // attrFetches = refill ticks / 1024, materialFetches = trace ticks / 1024, lightFetches = shade ticks / 1024, texDescFetches = rounds
+    unsigned long long tRefill = 0ull, tTrace = 0ull, tShade = 0ull, tMark = __builtin_readcyclecounter();
+    uint32_t rounds = 0u, dIter = 0u, dScan = 0u, dTri = 0u;
+    unsigned long long tScan = 0ull;
+#define PT_DIAG_INC(x) do { x++; } while (0)
+#define PT_DIAG_LAP(acc) do { const unsigned long long now_ = __builtin_readcyclecounter(); acc += now_ - tMark; tMark = now_; } while (0)
+#else
+#define PT_DIAG_LAP(acc) do { } while (0)
+#define PT_DIAG_INC(x) do { } while (0)
+#endif
 
     while (true) {
         // ---- (0) refill: a context without a pixel takes the next pixel of the frame and starts its first sample
@@ -1042,6 +1055,7 @@ __global__ __launch_bounds__(64, PT_WF_FUSED_WAVES) void pt_wf_fused(DScene S, P
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         __builtin_amdgcn_wave_barrier();
+        PT_DIAG_LAP(tRefill);
 
         // ---- (1) trace: resume what was parked, then scan the contexts' flag words kind-major and keep 64 traversals in flight
         {
@@ -1104,6 +1118,7 @@ __global__ __launch_bounds__(64, PT_WF_FUSED_WAVES) void pt_wf_fused(DScene S, P
             while (true) {
                 uint32_t nIdle = (uint32_t)__popcll(__ballot(!have));
                 while (cursor < nItems && (nIdle >= PT_WF_REFILL || nIdle == 64u)) {
+                    PT_DIAG_INC(dScan);
                     const unsigned long long idle = __ballot(!have);
                     const uint32_t rankI = rank_below(idle);
                     const uint32_t item = cursor + lane;
@@ -1146,11 +1161,12 @@ __global__ __launch_bounds__(64, PT_WF_FUSED_WAVES) void pt_wf_fused(DScene S, P
                 const bool mayPark = PT_WF_SUSPEND > 0u && exhausted && startedNew;
                 const uint32_t stopAt = !exhausted ? PT_WF_REFILL : (mayPark ? 64u - PT_WF_SUSPEND : 64u);
                 while (nIdle < stopAt) {
+                    PT_DIAG_INC(dIter);
                     const bool wantTri = have && rs.tg.y != 0u;
                     const uint32_t nT = (uint32_t)__popcll(__ballot(wantTri));
                     const uint32_t nN = (uint32_t)__popcll(__ballot(have && !wantTri));
                     bool fin = false;
-                    if ((nT >= PT_WF_TRI_PARK || nN == 0u) && wantTri) fin = ray_tri_one<STATS>(S, rs, cn);
+                    if ((nT >= PT_WF_TRI_PARK || nN == 0u) && wantTri) { PT_DIAG_INC(dTri); fin = ray_tri_one<STATS>(S, rs, cn); }
                     if (have && !fin && rs.tg.y == 0u) fin = ray_node_one<STATS>(S, rs, st, cn);
                     if (fin) finish();
                     nIdle = (uint32_t)__popcll(__ballot(!have));
@@ -1190,6 +1206,7 @@ __global__ __launch_bounds__(64, PT_WF_FUSED_WAVES) void pt_wf_fused(DScene S, P
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         __builtin_amdgcn_wave_barrier();
+        PT_DIAG_LAP(tTrace);
 
         // ---- (2) shade: every context whose rays have all returned
 #pragma unroll 1
@@ -1208,7 +1225,16 @@ __global__ __launch_bounds__(64, PT_WF_FUSED_WAVES) void pt_wf_fused(DScene S, P
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         __builtin_amdgcn_wave_barrier();
+        PT_DIAG_LAP(tShade);
+#ifdef PT_FUSED_DIAG
+        rounds++;
+#endif
     }
+#ifdef PT_FUSED_DIAG
+    if (lane == 0u) { cnt[5] = (uint32_t)(tRefill >> 10); cnt[6] = (uint32_t)(tTrace >> 10); cnt[7] = (uint32_t)(tShade >> 10); cnt[9] = rounds;
+                      cnt[8] = dIter; cnt[14] = dScan; cnt[15] = dTri; }
+    __builtin_amdgcn_wave_barrier();
+#endif
     // the wave's totals -> its counter row (a wave owns row blockIdx.x for the whole launch)
     __builtin_amdgcn_wave_barrier();
     if (lane < PT_NUM_COUNTERS) {
