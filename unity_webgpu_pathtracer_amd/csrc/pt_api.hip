@@ -177,9 +177,10 @@ int ensure_wavefront(PTContext* c, PTContext::WfSet& set, uint32_t numSlots, uin
     PTWfBuffers& B = set.wf;
     B.flags = (uint32_t*)carve(n * 4);
     B.rng = (uint32_t*)carve(n * 4);
-    float4** arrs[PT_F4_COUNT] = {&B.ro, &B.rd, &B.rad, &B.thr, &B.color, &B.neeO, &B.envD, &B.lightD, &B.envC, &B.lightC, &B.pthr, &B.hit, &B.hit2, &B.pixsum};   // PT_F4_* order
+    float4* dummy = nullptr;
+    float4** arrs[PT_F4_COUNT] = {&B.ray[0], &dummy, &B.ray[1], &dummy, &B.ray[2], &dummy, &B.rad, &B.thr, &B.color, &B.envC, &B.lightC, &B.pthr, &B.hit, &B.hit2, &B.pixsum};   // PT_F4_* order; a ray-record array spans two strides
     for (auto a : arrs) *a = (float4*)carve(n * 16);
-    B.f4base = B.ro;
+    B.f4base = B.ray[0];
     B.f4stride = (uint32_t)(align(n * 16) / 16);
     B.occl = (uint8_t*)carve(n * 2);
     B.aliveFlags = (uint32_t*)carve((size_t)maxIterations * 4);

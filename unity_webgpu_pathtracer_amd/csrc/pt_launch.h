@@ -61,7 +61,12 @@ hipError_t pt_launch_copy_texture(const float4* dTexture, uint32_t width, uint32
 hipError_t pt_launch_present(const PTPresentParams& Q, const float4* src, float4* dst, hipStream_t stream);
 
 // ---- schedule 1 (wavefront): slot-indexed path state in HBM (see pt_wavefront.hip) ----
-enum : uint32_t { PT_F4_RO = 0, PT_F4_RD, PT_F4_RAD, PT_F4_THR, PT_F4_COLOR, PT_F4_NEEO, PT_F4_ENVD, PT_F4_LIGHTD, PT_F4_ENVC, PT_F4_LIGHTC,
+// float4 arrays of a state set, in carving order.  PT_F4_RAY0/1/2 are the RAY RECORDS of the three ray kinds a slot can have in
+// flight (bounce ray, environment NEE, light NEE): 32 bytes per slot and kind, {origin.xyz, w0, direction.xyz, w1} at
+// float4 index 2 * slot -- so each takes TWO strides.  A trace lane fetches its ray as one 32-byte read inside one 64-byte
+// sector; round 2 kept origins and directions in separate 16-byte arrays and fetched two sectors per ray (12.2 GB of sectors
+// per pass for 2.9 GB of rays).  w0 / w1 of the bounce record carry scatterPdf / maxRoughness.
+enum : uint32_t { PT_F4_RAY0 = 0, PT_F4_RAY1 = 2, PT_F4_RAY2 = 4, PT_F4_RAD = 6, PT_F4_THR, PT_F4_COLOR, PT_F4_ENVC, PT_F4_LIGHTC,
                   PT_F4_PTHR, PT_F4_HIT, PT_F4_HIT2, PT_F4_PIXSUM, PT_F4_COUNT };
 #ifndef PT_WF_LDS_STACK
 #define PT_WF_LDS_STACK 8       // traversal-stack entries per lane kept in LDS by the refill / persistent trace kernels; deeper ones go to stackSpill
@@ -69,14 +74,13 @@ enum : uint32_t { PT_F4_RO = 0, PT_F4_RD, PT_F4_RAD, PT_F4_THR, PT_F4_COLOR, PT_
 struct PTWfBuffers {
     uint32_t* flags;            // [numSlots] packed state word
     uint32_t* rng;              // [numSlots]
-    float4 *ro, *rd;            // closest-hit ray in flight: (origin, scatterPdf), (direction, maxRoughness)
+    float4* ray[3];             // [2 * numSlots] each: ray records of kind 0 (bounce ray: origin, scatterPdf | direction, maxRoughness), 1 (environment NEE), 2 (light NEE)
     float4 *rad, *thr, *color;  // radiance, throughput, per-pixel sample sum
-    float4 *neeO, *envD, *lightD;        // NEE shadow rays of the last shaded bounce
-    float4 *envC, *lightC, *pthr;        // their contributions and the throughput they apply to
+    float4 *envC, *lightC, *pthr;        // contributions of the two NEE rays and the throughput they apply to
     float4* hit;                // [numSlots] (t, u, v, triIndex bits) written by trace kind 0
     float4* hit2;               // [numSlots] HAS_TLAS only: (world hit position, instance index bits)
     float4* pixsum;             // [numSlots] schedule 4 only: a finished pixel's sample sum, indexed by PIXEL slot (the other arrays by context)
-    // The thirteen float4 arrays above are carved back to back at a fixed stride: array k starts at f4base + k * f4stride
+    // The float4 arrays above are carved back to back at a fixed stride: array k starts at f4base + k * f4stride
     // (order: PT_F4_*).  The trace kernels address them this way -- one base pointer instead of seven -- because at 8 waves/SIMD a
     // wave may hold 80 SGPRs, and every pointer costs two.
     float4* f4base;

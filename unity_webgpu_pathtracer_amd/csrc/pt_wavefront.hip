@@ -40,19 +40,30 @@ PT_DEV uint32_t fl_light(uint32_t f) { return (f >> 5) & 1u; }
 PT_DEV float4 f4(v3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
 PT_DEV v3 xyz(float4 v) { return mk3(v.x, v.y, v.z); }
 
+// float4 state array k of the set (pt_launch.h PT_F4_*), addressed from ONE base pointer
+PT_DEV float4* f4_array(const PTWfBuffers& B, uint32_t k) { return B.f4base + (size_t)k * B.f4stride; }
+// the ray of (slot, kind): bounce ray (ro, rd), environment NEE (neeO, envD) or light NEE (neeO, lightD)
+PT_DEV void fetch_ray(const PTWfBuffers& B, uint32_t slot, uint32_t kind, v3& o, v3& d)
+{
+    const float4* rec = f4_array(B, 2u * kind) + 2u * (size_t)slot;          // PT_F4_RAY0 / 1 / 2: one 32-byte record, one sector
+    o = xyz(rec[0]);
+    d = xyz(rec[1]);
+}
+
 PT_DEV void store_path(const PTWfBuffers& B, uint32_t slot, const PathRegs& r, bool writeNee)
 {
     B.flags[slot] = pack_flags(r);
     B.rng[slot] = r.rng;
-    B.ro[slot] = f4(r.ro, r.scatterPdf);
-    B.rd[slot] = f4(r.rd, r.maxRoughness);
+    B.ray[0][2u * slot] = f4(r.ro, r.scatterPdf);
+    B.ray[0][2u * slot + 1u] = f4(r.rd, r.maxRoughness);
     B.rad[slot] = f4(r.radiance, 0.0f);
     B.thr[slot] = f4(r.throughput, 0.0f);
     B.color[slot] = f4(r.color, 0.0f);
     if (writeNee) {
-        B.neeO[slot] = f4(r.neeOrigin, 0.0f);
-        B.envD[slot] = f4(r.env.dir, 0.0f);
-        B.lightD[slot] = f4(r.light.dir, 0.0f);
+        B.ray[1][2u * slot] = f4(r.neeOrigin, 0.0f);
+        B.ray[1][2u * slot + 1u] = f4(r.env.dir, 0.0f);
+        B.ray[2][2u * slot] = f4(r.neeOrigin, 0.0f);
+        B.ray[2][2u * slot + 1u] = f4(r.light.dir, 0.0f);
         B.envC[slot] = f4(r.env.contribution, 0.0f);
         B.lightC[slot] = f4(r.light.contribution, 0.0f);
         B.pthr[slot] = f4(r.pendThroughput, 0.0f);
@@ -123,8 +134,7 @@ __global__ __launch_bounds__(256, 4) void pt_wf_trace(DScene S, PTWfBuffers B)
     Counters cn = {};
     if (valid) {
         v3 o, d;
-        if (kind == 0u) { o = xyz(B.ro[slot]); d = xyz(B.rd[slot]); }
-        else { o = xyz(B.neeO[slot]); d = xyz(kind == 1u ? B.envD[slot] : B.lightD[slot]); }
+        fetch_ray(B, slot, kind, o, d);
         TravStack st;
         st.lds = &s_stack[0][threadIdx.x];
         st.stride = 256u;
@@ -183,15 +193,6 @@ static_assert(PT_WF_RANGE >= 64u && (PT_WF_RANGE & (PT_WF_RANGE - 1u)) == 0u,
 PT_DEV uint32_t rank_below(unsigned long long m)
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
-
-// float4 state array k of the set (pt_launch.h PT_F4_*), addressed from ONE base pointer
-PT_DEV float4* f4_array(const PTWfBuffers& B, uint32_t k) { return B.f4base + (size_t)k * B.f4stride; }
-// the ray of (slot, kind): bounce ray (ro, rd), environment NEE (neeO, envD) or light NEE (neeO, lightD)
-PT_DEV void fetch_ray(const PTWfBuffers& B, uint32_t slot, uint32_t kind, v3& o, v3& d)
-{
-    o = xyz(f4_array(B, kind == 0u ? PT_F4_RO : PT_F4_NEEO)[slot]);
-    d = xyz(f4_array(B, kind == 0u ? PT_F4_RD : (kind == 1u ? PT_F4_ENVD : PT_F4_LIGHTD))[slot]);
 }
 
 // Result stores of the trace kernels.  The empty asm pins the address arithmetic (and the constant miss record) to the
@@ -577,7 +578,7 @@ __global__ __launch_bounds__(64, PT_WF_TLAS_MIN_WAVES) void pt_wf_trace_refill_t
                         const float4 w0 = ip[4], w1 = ip[5], w2 = ip[6], w3 = ip[7], ints = ip[8];
                         if (STATS) cn.instanceVisits++;
                         nodeOffset = pt_asuint(ints.x); triOffset = pt_asuint(ints.y); attrOffset = pt_asuint(ints.z);
-                        const v3 wd = xyz(f4_array(B, myKind == 0u ? PT_F4_RD : (myKind == 1u ? PT_F4_ENVD : PT_F4_LIGHTD))[mySlot]);
+                        const v3 wd = xyz(f4_array(B, 2u * myKind)[2u * (size_t)mySlot + 1u]);           // the direction row of the lane's ray record
                         const v4 lo4 = mul44c(w0, w1, w2, w3, v4{O.x, O.y, O.z, 1.0f});
                         const v4 ld4 = mul44c(w0, w1, w2, w3, v4{wd.x, wd.y, wd.z, 0.0f});
                         const float tKeep = rs.hit.t;
@@ -813,8 +814,8 @@ PT_DEV void load_path(const PTWfBuffers& B, uint32_t slot, uint32_t f, PathRegs&
     r.depth = f >> 19;
     r.rng = B.rng[slot];
     float4 q;
-    q = B.ro[slot]; r.ro = xyz(q); r.scatterPdf = q.w;
-    q = B.rd[slot]; r.rd = xyz(q); r.maxRoughness = q.w;
+    q = B.ray[0][2u * slot]; r.ro = xyz(q); r.scatterPdf = q.w;
+    q = B.ray[0][2u * slot + 1u]; r.rd = xyz(q); r.maxRoughness = q.w;
     r.radiance = xyz(B.rad[slot]);
     r.throughput = xyz(B.thr[slot]);
     r.color = xyz(B.color[slot]);
@@ -842,7 +843,7 @@ PT_DEV bool shade_slot(const DScene& S, const PTFrameParams& P, const PTTileMap&
     uint32_t px, py;
     pt_slot_to_pixel(tm, pixelSlot, px, py);
     uint32_t rng = B.rng[slot];
-    float4 qro = B.ro[slot], qrd = B.rd[slot], qrad = B.rad[slot], qthr = B.thr[slot], qcol = B.color[slot];
+    float4 qro = B.ray[0][2u * slot], qrd = B.ray[0][2u * slot + 1u], qrad = B.rad[slot], qthr = B.thr[slot], qcol = B.color[slot];
     float4 qenvC = B.envC[slot], qlightC = B.lightC[slot], qpthr = B.pthr[slot], qhit = B.hit[slot];
     uint32_t o0 = B.occl[slot], o1 = B.occl[(size_t)B.numSlots + slot];
     float4 qhit2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -882,9 +883,10 @@ PT_DEV bool shade_slot(const DScene& S, const PTFrameParams& P, const PTTileMap&
         PT_DEV void operator()(PathRegs& q) const {
             uint32_t s2 = slot;
             asm volatile("" : "+v"(s2));
-            B.neeO[s2] = f4(q.neeOrigin, 0.0f);
-            B.envD[s2] = f4(q.env.dir, 0.0f);
-            B.lightD[s2] = f4(q.light.dir, 0.0f);
+            B.ray[1][2u * s2] = f4(q.neeOrigin, 0.0f);
+            B.ray[1][2u * s2 + 1u] = f4(q.env.dir, 0.0f);
+            B.ray[2][2u * s2] = f4(q.neeOrigin, 0.0f);
+            B.ray[2][2u * s2 + 1u] = f4(q.light.dir, 0.0f);
             B.envC[s2] = f4(q.env.contribution, 0.0f);
             B.lightC[s2] = f4(q.light.contribution, 0.0f);
             B.pthr[s2] = f4(q.pendThroughput, 0.0f);
@@ -1263,9 +1265,9 @@ __global__ __launch_bounds__(256, 2) void pt_wf_cleanup(DScene S, PTFrameParams 
             PathRegs r;
             load_path(B, slot, f, r);
             if (r.hasPending) {
-                r.neeOrigin = xyz(B.neeO[slot]);
-                r.env.dir = xyz(B.envD[slot]);
-                r.light.dir = xyz(B.lightD[slot]);
+                r.neeOrigin = xyz(B.ray[1][2u * slot]);
+                r.env.dir = xyz(B.ray[1][2u * slot + 1u]);
+                r.light.dir = xyz(B.ray[2][2u * slot + 1u]);
             }
             TravStack st;
             st.lds = &s_stack[0][threadIdx.x];
