@@ -111,6 +111,7 @@ struct PTContext {
     uint32_t nextSet = 0;
     uint32_t numSets = 0;                       // passes in flight = state sets in use (PTSetPassesInFlight); carved on first use
     uint32_t wfIterations = 0;                  // 0 = automatic
+    uint32_t tailCut = PT_WF_TAIL_CUT;          // wavefront tail cut (pt_wavefront.hip tail_cut); PT_WF_TAIL_CUT in the environment overrides (experiments)
 };
 
 namespace {
@@ -151,6 +152,7 @@ int ensure_wavefront(PTContext* c, PTContext::WfSet& set, uint32_t numSlots, uin
         HIP_TRY(hipEventCreateWithFlags(&set.done, hipEventDisableTiming));
     }
     const bool needTlas = c->scene.hasTlas != 0u;
+    set.wf.tailCut = c->tailCut;
     if (set.wf.flags && set.wf.numSlots == numSlots && set.wf.maxIterations >= maxIterations && (!needTlas || set.wf.tlasSpill)) return PT_OK;
     HIP_TRY(hipStreamSynchronize(set.stream));
     const size_t n = numSlots;
@@ -165,7 +167,7 @@ int ensure_wavefront(PTContext* c, PTContext::WfSet& set, uint32_t numSlots, uin
     const size_t spillBytes = traceWaves * 64u * (size_t)(PT_BVH_STACK_SIZE - PT_WF_LDS_STACK) * sizeof(uint2);
     const size_t suspBytes = traceWaves * (size_t)(PT_WF_SUSPEND ? PT_WF_SUSPEND : 1u) * 6 * sizeof(uint4);
     const size_t tlasSpillBytes = needTlas ? traceWaves * 64u * (size_t)PT_BVH_STACK_SIZE * sizeof(uint32_t) : 0;
-    size_t total = align(n * 4) * 2 + align(n * 16) * PT_F4_COUNT + align(n * 2) + align((size_t)maxIterations * 4) +
+    size_t total = align(n * 4) * 2 + align(n * 16) * PT_F4_COUNT + align(n * 2) + align((size_t)maxIterations * 4 * PT_WF_ALIVE_SHARDS) +
                    align((size_t)numRows * 16 * 8) + align(8 * 32 * 4) + align(spillBytes) + align(suspBytes) + align(traceWaves * 4) + align(tlasSpillBytes);
     if (set.arena && set.arenaBytes < total) { hipFree(set.arena); set.arena = nullptr; set.arenaBytes = 0; }
     if (!set.arena) {
@@ -183,7 +185,7 @@ int ensure_wavefront(PTContext* c, PTContext::WfSet& set, uint32_t numSlots, uin
     B.f4base = B.ray[0];
     B.f4stride = (uint32_t)(align(n * 16) / 16);
     B.occl = (uint8_t*)carve(n * 2);
-    B.aliveFlags = (uint32_t*)carve((size_t)maxIterations * 4);
+    B.aliveFlags = (uint32_t*)carve((size_t)maxIterations * 4 * PT_WF_ALIVE_SHARDS);
     B.statRows = (unsigned long long*)carve((size_t)numRows * 16 * 8);
     B.chunkHeads = (uint32_t*)carve(8 * 32 * 4);
     B.stackSpill = (uint2*)carve(spillBytes);
@@ -191,6 +193,7 @@ int ensure_wavefront(PTContext* c, PTContext::WfSet& set, uint32_t numSlots, uin
     B.suspCount = (uint32_t*)carve(traceWaves * 4);
     B.tlasSpill = needTlas ? (uint32_t*)carve(tlasSpillBytes) : nullptr;
     B.residentWaves = residentWaves;
+    B.tailCut = c->tailCut;
     B.numSlots = numSlots;
     B.numStatRows = numRows;
     B.maxIterations = maxIterations;
@@ -460,6 +463,7 @@ PT_API int PTCreate(int deviceIndex, PTContext** outCtx)
     PTContext* c = new PTContext();
     c->device = deviceIndex;
     c->numSets = default_passes_in_flight();
+    if (const char* e = getenv("PT_WF_TAIL_CUT")) c->tailCut = (uint32_t)strtoul(e, nullptr, 10);
     hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (se != hipSuccess) { delete c; return fail(PT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(se)); }
     se = hipMalloc((void**)&c->dStats, 16 * sizeof(unsigned long long));

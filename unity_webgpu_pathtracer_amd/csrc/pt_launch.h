@@ -90,7 +90,8 @@ struct PTWfBuffers {
     uint32_t* tlasSpill;        // [numSlots][32]: HAS_TLAS refill kernel, TLAS-stack entries beyond its LDS part (allocated for HAS_TLAS scenes only)
     uint4* susp;                // [numSlots / 64][PT_WF_SUSPEND][6]: suspended rays of the refill trace kernel (pt_wavefront.hip)
     uint32_t* suspCount;        // [numSlots / 64]
-    uint32_t* aliveFlags;       // [maxIterations]
+    uint32_t* aliveFlags;       // [maxIterations][PT_WF_ALIVE_SHARDS] slots still alive after shade launch i of the pass (tail cut, pt_wavefront.hip)
+    uint32_t tailCut;           // later launches of a pass return at once when fewer slots than this are alive; pt_wf_cleanup finishes them
     uint32_t* chunkHeads;       // [8 shards x 32 words]: work counters of the persistent trace kernel, one 128-B line each
     unsigned long long* statRows;   // [numStatRows][16]
     uint32_t numSlots, numStatRows, maxIterations;
@@ -124,6 +125,10 @@ hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const fl
 #ifndef PT_WF_SUSPEND
 #define PT_WF_SUSPEND 16u       // refill trace kernel: a wave whose range is exhausted stops when this many rays or fewer are left, and leaves them
                                 // as records for the tail launch (pt_wavefront.hip); 0 = off.  Also the record slots per trace wave (pt_api.hip)
+#endif
+#define PT_WF_ALIVE_SHARDS 64u   // words per iteration of PTWfBuffers.aliveFlags (power of two <= 64)
+#ifndef PT_WF_TAIL_CUT
+#define PT_WF_TAIL_CUT 0u        // 0 = never cut (every launch of the fixed sequence runs)
 #endif
 #ifndef PT_WF_SETS
 #define PT_WF_SETS 12            // path-state sets = passes that can be in flight at once, each on its own stream (3 -> 6 sets with 8 hardware queues: +12 %;

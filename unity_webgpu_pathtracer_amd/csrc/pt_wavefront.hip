@@ -70,6 +70,20 @@ PT_DEV void store_path(const PTWfBuffers& B, uint32_t slot, const PathRegs& r, b
     }
 }
 
+// Tail cut: B.aliveFlags[i] = number of slots still alive after shade launch i (zeroed at the start of a pass).  Once that
+// drops below B.tailCut, every later trace / shade launch of the pass returns at its first instruction and pt_wf_cleanup runs
+// the stragglers to completion: the last ~20 of the 52 iterations of a pass used to cost ~170 us each (the latency of the
+// longest surviving ray, three launches per iteration) for a handful of rays.  Wave-uniform, no host synchronisation.
+// The count is kept in PT_WF_ALIVE_SHARDS words per iteration (a wave adds to word blockIdx % SHARDS): 32,000 atomics per
+// launch on ONE word serialise in one L2 channel and doubled the time of a pass.
+PT_DEV bool tail_cut(const PTWfBuffers& B, uint32_t iteration)
+{
+    if (iteration == 0u || B.tailCut == 0u) return false;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t part = lane < PT_WF_ALIVE_SHARDS ? B.aliveFlags[(iteration - 1u) * PT_WF_ALIVE_SHARDS + lane] : 0u;
+    return wave_sum_u32(part) < B.tailCut;
+}
+
 // per-wave counter rows: one wave owns a row, so a plain read-modify-write is race-free across launches of one stream
 template <bool STATS>
 PT_DEV void flush_counters(const Counters& cn, unsigned long long* rows, uint32_t row, uint32_t lane)
@@ -119,9 +133,10 @@ __global__ __launch_bounds__(256) void pt_wf_init(PTFrameParams P, PTTileMap tm,
 #endif
 
 template <bool STATS, bool TLAS>
-__global__ __launch_bounds__(256, 4) void pt_wf_trace(DScene S, PTWfBuffers B)
+__global__ __launch_bounds__(256, 4) void pt_wf_trace(DScene S, PTWfBuffers B, uint32_t iteration)
 {
     __shared__ uint2 s_stack[PT_LDS_STACK][256];
+    if (tail_cut(B, iteration)) return;
     const uint32_t nb = B.numSlots >> 8;
     const uint32_t vb = blockIdx.x;
     const uint32_t kind = vb / nb;
@@ -250,9 +265,10 @@ PT_DEV void suspend_ray(const PTWfBuffers& B, uint32_t rec, uint32_t slot, uint3
 
 // RANGE: slots per wave (64 or 128; pt_launch_wavefront picks by the size of the launch)
 template <bool STATS, bool TAIL, uint32_t RANGE>
-__global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(DScene S, PTWfBuffers B)
+__global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(DScene S, PTWfBuffers B, uint32_t iteration)
 {
     __shared__ uint2 s_stack[PT_WF_LDS_STACK][64];
+    if (tail_cut(B, iteration)) return;                               // main and tail launch of an iteration decide alike
     __shared__ uint32_t s_xchg[TAIL ? PT_WF_TAIL_GROUP * (PT_WF_SUSPEND ? PT_WF_SUSPEND : 1u) : 64u];
     // the wave's counter row is parked in LDS until the end: kept in a register it is the one value the compiler spilled to
     // scratch, and ANY scratch costs this kernel its occupancy (see TravStackT)
@@ -481,9 +497,10 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(
 #define PT_WF_TLAS_MIN_WAVES 6      // 80 VGPRs, no scratch (without the SLP vectorizer); 5 waves: -3 %
 #endif
 template <bool STATS>
-__global__ __launch_bounds__(64, PT_WF_TLAS_MIN_WAVES) void pt_wf_trace_refill_tlas(DScene S, PTWfBuffers B)
+__global__ __launch_bounds__(64, PT_WF_TLAS_MIN_WAVES) void pt_wf_trace_refill_tlas(DScene S, PTWfBuffers B, uint32_t iteration)
 {
     __shared__ uint2 s_stack[PT_WF_LDS_STACK][64];
+    if (tail_cut(B, iteration)) return;
     __shared__ uint32_t s_tstack[PT_WF_TLAS_LDS_STACK][64];
     __shared__ uint32_t s_xchg[64];
     __shared__ uint32_t s_gw;
@@ -709,9 +726,10 @@ PT_DEV bool next_chunk(uint32_t* heads, uint32_t numChunks, uint32_t shard, uint
 }
 
 template <bool STATS>
-__global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_persist(DScene S, PTWfBuffers B)
+__global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_persist(DScene S, PTWfBuffers B, uint32_t iteration)
 {
     __shared__ uint2 s_stack[PT_WF_LDS_STACK][64];
+    if (tail_cut(B, iteration)) return;
     __shared__ uint32_t s_xchg[64];
     const uint32_t lane = threadIdx.x;
     const uint32_t numChunks = (B.numSlots + PT_WF_CHUNK - 1u) / PT_WF_CHUNK;
@@ -919,6 +937,7 @@ __global__ __launch_bounds__(PT_WF_SHADE_BLOCK, PT_WF_SHADE_MIN_WAVES) void pt_w
     const uint32_t vb = blockIdx.x;
     const uint32_t slot = vb * PT_WF_SHADE_BLOCK + threadIdx.x;
     if (vb == 0u && threadIdx.x < PT_WF_SHARDS) B.chunkHeads[threadIdx.x * 32u] = 0u;   // for the next trace launch (schedule 3)
+    if (tail_cut(B, iteration)) return;                               // (aliveFlags[iteration] stays 0: the later launches return too)
     const uint32_t f = B.flags[slot];
     Counters cn = {};
     bool alive = false;
@@ -928,7 +947,11 @@ __global__ __launch_bounds__(PT_WF_SHADE_BLOCK, PT_WF_SHADE_MIN_WAVES) void pt_w
     if (fl_state(f) != PS_DONE) cn.instanceVisits++;
 #endif
     if (fl_state(f) != PS_DONE) alive = shade_slot<STATS>(S, P, tm, B, slot, slot, f, cn);
-    if (__any(alive) && (threadIdx.x & 63u) == 0u) B.aliveFlags[iteration] = 1u;     // diagnostics: last iteration anybody needed
+    {
+        const uint32_t nAlive = (uint32_t)__popcll(__ballot(alive));
+        if (B.tailCut != 0u && nAlive && (threadIdx.x & 63u) == 0u)
+            atomicAdd(&B.aliveFlags[iteration * PT_WF_ALIVE_SHARDS + (blockIdx.x & (PT_WF_ALIVE_SHARDS - 1u))], nAlive);   // one atomic per wave that still has paths
+    }
     flush_counters<STATS>(cn, B.statRows, vb * (PT_WF_SHADE_BLOCK / 64u) + (threadIdx.x >> 6), threadIdx.x & 63u);
 }
 
@@ -1392,7 +1415,7 @@ hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const fl
         if (launchesOut) *launchesOut = 3u;
         return hipGetLastError();
     }
-    if ((e = hipMemsetAsync(B.aliveFlags, 0, sizeof(uint32_t) * B.maxIterations, stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(B.aliveFlags, 0, sizeof(uint32_t) * B.maxIterations * PT_WF_ALIVE_SHARDS, stream)) != hipSuccess) return e;
     hipLaunchKernelGGL(pt_wf_init, dim3(nb), dim3(256), 0, stream, P, tm, B);
     launches++;
     const uint32_t spp = P.SamplesPerPass > 1 ? (uint32_t)P.SamplesPerPass : 1u;
@@ -1406,38 +1429,38 @@ hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const fl
             const uint32_t numChunks = (B.numSlots + PT_WF_CHUNK - 1u) / PT_WF_CHUNK;
             uint32_t waves = B.residentWaves;
             if (waves > numChunks) waves = numChunks;
-            if (fullStats) hipLaunchKernelGGL(pt_wf_trace_persist<true>, dim3(waves), dim3(64), 0, stream, S, B);
-            else hipLaunchKernelGGL(pt_wf_trace_persist<false>, dim3(waves), dim3(64), 0, stream, S, B);
+            if (fullStats) hipLaunchKernelGGL(pt_wf_trace_persist<true>, dim3(waves), dim3(64), 0, stream, S, B, it);
+            else hipLaunchKernelGGL(pt_wf_trace_persist<false>, dim3(waves), dim3(64), 0, stream, S, B, it);
         } else if (traceVariant == 2) {
             const bool wide = PT_WF_RANGE >= 128u && pt_wf_wide_ranges(B.numSlots, B.residentWaves);         // pt_launch.h
             const uint32_t blocks = wide ? (B.numSlots + 127u) / 128u : (B.numSlots + 63u) / 64u;
             if (wide) {
-                if (fullStats) hipLaunchKernelGGL((pt_wf_trace_refill<true, false, 128u>), dim3(blocks), dim3(64), 0, stream, S, B);
-                else hipLaunchKernelGGL((pt_wf_trace_refill<false, false, 128u>), dim3(blocks), dim3(64), 0, stream, S, B);
+                if (fullStats) hipLaunchKernelGGL((pt_wf_trace_refill<true, false, 128u>), dim3(blocks), dim3(64), 0, stream, S, B, it);
+                else hipLaunchKernelGGL((pt_wf_trace_refill<false, false, 128u>), dim3(blocks), dim3(64), 0, stream, S, B, it);
             } else {
-                if (fullStats) hipLaunchKernelGGL((pt_wf_trace_refill<true, false, 64u>), dim3(blocks), dim3(64), 0, stream, S, B);
-                else hipLaunchKernelGGL((pt_wf_trace_refill<false, false, 64u>), dim3(blocks), dim3(64), 0, stream, S, B);
+                if (fullStats) hipLaunchKernelGGL((pt_wf_trace_refill<true, false, 64u>), dim3(blocks), dim3(64), 0, stream, S, B, it);
+                else hipLaunchKernelGGL((pt_wf_trace_refill<false, false, 64u>), dim3(blocks), dim3(64), 0, stream, S, B, it);
             }
             if (PT_WF_SUSPEND > 0u) {
                 const uint32_t tailBlocks = (blocks + PT_WF_TAIL_GROUP - 1u) / PT_WF_TAIL_GROUP;
                 if (wide) {
-                    if (fullStats) hipLaunchKernelGGL((pt_wf_trace_refill<true, true, 128u>), dim3(tailBlocks), dim3(64), 0, stream, S, B);
-                    else hipLaunchKernelGGL((pt_wf_trace_refill<false, true, 128u>), dim3(tailBlocks), dim3(64), 0, stream, S, B);
+                    if (fullStats) hipLaunchKernelGGL((pt_wf_trace_refill<true, true, 128u>), dim3(tailBlocks), dim3(64), 0, stream, S, B, it);
+                    else hipLaunchKernelGGL((pt_wf_trace_refill<false, true, 128u>), dim3(tailBlocks), dim3(64), 0, stream, S, B, it);
                 } else {
-                    if (fullStats) hipLaunchKernelGGL((pt_wf_trace_refill<true, true, 64u>), dim3(tailBlocks), dim3(64), 0, stream, S, B);
-                    else hipLaunchKernelGGL((pt_wf_trace_refill<false, true, 64u>), dim3(tailBlocks), dim3(64), 0, stream, S, B);
+                    if (fullStats) hipLaunchKernelGGL((pt_wf_trace_refill<true, true, 64u>), dim3(tailBlocks), dim3(64), 0, stream, S, B, it);
+                    else hipLaunchKernelGGL((pt_wf_trace_refill<false, true, 64u>), dim3(tailBlocks), dim3(64), 0, stream, S, B, it);
                 }
                 launches++;
             }
         } else if (tlas && tlasRefill) {
-            if (fullStats) hipLaunchKernelGGL(pt_wf_trace_refill_tlas<true>, dim3(refillBlocks), dim3(64), 0, stream, S, B);
-            else hipLaunchKernelGGL(pt_wf_trace_refill_tlas<false>, dim3(refillBlocks), dim3(64), 0, stream, S, B);
+            if (fullStats) hipLaunchKernelGGL(pt_wf_trace_refill_tlas<true>, dim3(refillBlocks), dim3(64), 0, stream, S, B, it);
+            else hipLaunchKernelGGL(pt_wf_trace_refill_tlas<false>, dim3(refillBlocks), dim3(64), 0, stream, S, B, it);
         } else if (tlas) {
-            if (fullStats) hipLaunchKernelGGL((pt_wf_trace<true, true>), dim3(nb * 3u), dim3(256), 0, stream, S, B);
-            else hipLaunchKernelGGL((pt_wf_trace<false, true>), dim3(nb * 3u), dim3(256), 0, stream, S, B);
+            if (fullStats) hipLaunchKernelGGL((pt_wf_trace<true, true>), dim3(nb * 3u), dim3(256), 0, stream, S, B, it);
+            else hipLaunchKernelGGL((pt_wf_trace<false, true>), dim3(nb * 3u), dim3(256), 0, stream, S, B, it);
         } else {
-            if (fullStats) hipLaunchKernelGGL((pt_wf_trace<true, false>), dim3(nb * 3u), dim3(256), 0, stream, S, B);
-            else hipLaunchKernelGGL((pt_wf_trace<false, false>), dim3(nb * 3u), dim3(256), 0, stream, S, B);
+            if (fullStats) hipLaunchKernelGGL((pt_wf_trace<true, false>), dim3(nb * 3u), dim3(256), 0, stream, S, B, it);
+            else hipLaunchKernelGGL((pt_wf_trace<false, false>), dim3(nb * 3u), dim3(256), 0, stream, S, B, it);
         }
         if (fullStats) hipLaunchKernelGGL(pt_wf_shade<true>, dim3(B.numSlots / PT_WF_SHADE_BLOCK), dim3(PT_WF_SHADE_BLOCK), 0, stream, S, P, tm, B, it);
         else hipLaunchKernelGGL(pt_wf_shade<false>, dim3(B.numSlots / PT_WF_SHADE_BLOCK), dim3(PT_WF_SHADE_BLOCK), 0, stream, S, P, tm, B, it);
