@@ -162,6 +162,9 @@ def main():
     ap.add_argument("--passes-in-flight", type=int, default=0, help="PTSetPassesInFlight: 0 = library default for GPU_MAX_HW_QUEUES, 1 = passes back to back")
     ap.add_argument("--latency-steps", type=int, default=6, help="passes of the latency leg (host synchronises after every pass); 0 = skip")
     ap.add_argument("--build-device", action="store_true", help="also render over the tree PTBuildBVHDevice builds on the GPU (reported under 'device_built_tree')")
+    ap.add_argument("--batch", type=int, default=0, help="passes per launch sequence (PTRenderPassBatchTo, 1..8): the steps are issued in groups of this many -- same frames, "
+                                                         "larger launches.  0 (default) = 1 on one GPU, min(N, 8) on N GPUs, where one rank's share of ONE pass is too small "
+                                                         "a launch to fill an MI355X (1/8 of a 1080p pass: 2.92 ms alone, 2.28 ms per pass in batches of eight)")
     ap.add_argument("--master-port", type=int, default=29671, help="rendezvous port when bench.py launches its own ranks")
     args = ap.parse_args()
 
@@ -204,6 +207,9 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     W, H, SPP = args.width, args.height, args.spp
+    if args.batch <= 0:
+        args.batch = 1 if world == 1 else min(world, 8)
+    args.batch = min(args.batch, 8)
 
     def run_workload(name, steps, warmup, full, build_device=None):
         wl = WORKLOADS[name]
@@ -223,9 +229,14 @@ def main():
         ext = torch.cuda.ExternalStream(pt.stream(), device=device)
         torch.cuda.synchronize(device)
 
-        def step(k, cur):
-            p = scenes.frame_params(scene, W, H, spp=SPP, current_sample=k * SPP, seed=seed_of(k), max_bounces=args.bounces)
-            pt.render_pass_to(p, frames[cur].data_ptr(), frames[1 - cur].data_ptr() if k > 0 else 0)
+        def step(k, cur, count=1):
+            """passes k .. k + count - 1 into frames[cur] (accumulated frame: frames[1 - cur])"""
+            ps = [scenes.frame_params(scene, W, H, spp=SPP, current_sample=(k + j) * SPP, seed=seed_of(k + j), max_bounces=args.bounces) for j in range(count)]
+            p = ps[-1]
+            if count == 1:
+                pt.render_pass_to(p, frames[cur].data_ptr(), frames[1 - cur].data_ptr() if k > 0 else 0)
+            else:
+                pt.render_batch_to(ps, frames[cur].data_ptr(), frames[1 - cur].data_ptr() if k > 0 else 0)
             if distributed:
                 with torch.cuda.stream(ext):                                  # pack -> RCCL gather over xGMI -> unpack, once per frame
                     dist_helpers.gather_frame(frames[cur], rank, world, dst=0, assembled=assembled, pt=pt, params=p, scratch=scratch)
@@ -237,10 +248,17 @@ def main():
                 dist.barrier()
                 torch.cuda.synchronize(device)
 
-        cur = 0
-        for k in range(warmup):
-            step(k, cur)
-            cur = 1 - cur
+        def run_steps(k0, k1, cur):
+            """steps k0 .. k1 - 1 in groups of --batch passes (the last group may be shorter)"""
+            k = k0
+            while k < k1:
+                n = min(max(1, args.batch), k1 - k)
+                step(k, cur, n)
+                cur = 1 - cur
+                k += n
+            return cur
+
+        cur = run_steps(0, warmup, 0)
         sync_all()
         pt.reset_stats()
         pt.set_profiling(True)
@@ -249,9 +267,7 @@ def main():
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record(ext)              # HIP events on the context's own stream, which every pass joins when it completes
-        for k in range(warmup, warmup + steps):
-            step(k, cur)
-            cur = 1 - cur
+        cur = run_steps(warmup, warmup + steps, cur)
         ev1.record(ext)
         sync_all()
         elapsed = time.perf_counter() - t0
@@ -362,7 +378,7 @@ def main():
                                    f"progressive passes (CurrentSample = 8k)",
                        "tris": main_res["tris"], "rays_per_step": round(main_res["rays_per_step"]),
                        "msamples_per_s": round(main_res["msamples_per_s"], 3), "schedule": main_res["schedule"],
-                       "passes_in_flight": main_res["passes_in_flight"],
+                       "passes_in_flight": main_res["passes_in_flight"], "passes_per_launch_sequence": max(1, args.batch),
                        "frame_crc32": main_res["frame_crc32"],
                        "sharding": "interleaved 16x16 blocks, one RCCL gather of owned tiles per frame" if distributed else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

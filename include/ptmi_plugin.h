@@ -249,6 +249,16 @@ PT_API int PTResetFrames(PTContext* ctx);      /* Reset(): _currentRT = 0      (
  * dOutput is written, dAccumulated (may be NULL when CurrentSample == 0) is read. */
 PT_API int PTRenderPassTo(PTContext* ctx, const PTFrameParams* params, void* dOutput, const void* dAccumulated);
 
+/* `count` consecutive progressive passes (1..8) enqueued as ONE launch sequence: params[j] are the uniforms of pass j and may
+ * differ in RngSeedRoot and CurrentSample only.  The result in dOutput is bit-identical to calling PTRenderPassTo `count` times
+ * with the caller ping-ponging two frames (pass j reads what pass j-1 wrote; pass 0 reads dAccumulated when its CurrentSample > 0):
+ * the paths of different passes are independent and the running mean of PathTracer.compute:89-98 is applied pass by pass in the
+ * resolve kernel -- only the intermediate frames are never stored.  For offline / converging renders (the reference keeps
+ * dispatching passes until _maxSamples, PathTracer.cs:194-272) and for tile-sharded rendering, where one rank's share of one
+ * pass is too small a launch to fill an MI355X: eight passes of a 1/8 share are one whole frame's worth of paths.  PTStats counts
+ * pixelsWritten / pixelsRead as the `count` separate passes would. */
+PT_API int PTRenderPassBatchTo(PTContext* ctx, const PTFrameParams* params, int count, void* dOutput, const void* dAccumulated);
+
 /* Block until every pass launched so far has finished. */
 PT_API int PTSynchronize(PTContext* ctx);
 /* Copy the current Output frame (frame[cur]) to host memory: width*height float4. */

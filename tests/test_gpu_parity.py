@@ -216,6 +216,45 @@ def test_pipelined_passes_without_host_sync(oracle, schedule):
     pt.close()
 
 
+@pytest.mark.parametrize("schedule", [0, 1, 4])
+def test_pass_batch_equals_sequential_passes(schedule):
+    """PTRenderPassBatchTo: k progressive passes as ONE launch sequence (slots = passes x pixels; the resolve kernel applies the
+    running mean pass by pass) against the same passes issued one by one with the caller ping-ponging frames: identical bits,
+    identical ray counters.  Also across a batch boundary (the second batch starts at CurrentSample > 0) and with tile ownership."""
+    import torch
+    s = scenes.material_zoo()
+    W, H, SPP = 136, 88, 2                                        # not multiples of 16: partially covered edge blocks
+    seeds = [(0x12345678 + k * 0x9E3779B9) & 0xFFFFFFFF for k in range(7)]
+    for rank, world in ((0, 1), (1, 3)):
+        pt = PathTracer(s, width=W, height=H, samplesPerPass=SPP, schedule=schedule, rank=rank, world_size=world)
+        frames = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+        params = [scenes.frame_params(s, W, H, spp=SPP, current_sample=k * SPP, seed=seeds[k]) for k in range(7)]
+        cur = 0
+        for k in range(7):                                           # reference: one pass per call
+            pt.render_pass_to(params[k], frames[cur].data_ptr(), frames[1 - cur].data_ptr() if k > 0 else 0)
+            cur = 1 - cur
+        pt.synchronize()
+        ref = frames[1 - cur].cpu().numpy().copy()
+        st_ref = pt.stats()
+        pt.reset_stats()
+        a = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        b = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        pt.render_batch_to(params[0:3], a.data_ptr(), 0)             # passes 0-2
+        pt.render_batch_to(params[3:4], b.data_ptr(), a.data_ptr())  # a batch of one
+        pt.render_batch_to(params[4:7], a.data_ptr(), b.data_ptr())  # passes 4-6, accumulated frame given
+        pt.synchronize()
+        got = a.cpu().numpy()
+        st = pt.stats()
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (schedule, rank, world)
+        assert (st.rays, st.paths, st.closestHitRays, st.shadowRays) == (st_ref.rays, st_ref.paths, st_ref.closestHitRays, st_ref.shadowRays)
+        assert st.pixelsWritten == st_ref.pixelsWritten and st.pixelsRead == st_ref.pixelsRead
+        # passes that differ in anything but RngSeedRoot / CurrentSample are refused
+        bad = [params[0], scenes.frame_params(s, W, H, spp=SPP, current_sample=SPP, seed=1, max_bounces=2)]
+        with pytest.raises(Exception):
+            pt.render_batch_to(bad, a.data_ptr(), 0)
+        pt.close()
+
+
 def test_render_pass_to_caller_buffers(oracle):
     """PTRenderPassTo with caller-owned device frames (torch tensors), ping-ponged by the caller as bench.py does."""
     import torch

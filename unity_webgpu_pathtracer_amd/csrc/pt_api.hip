@@ -85,6 +85,8 @@ struct PTContext {
     int device = 0;
     hipStream_t stream = nullptr;
     DeviceBuffer nodes, tris, attrs, materials, lights, lightConst, tex, tlas, instances, envTex, envCdf;
+    void* batchScratch = nullptr;               // PTRenderPassBatchTo under the megakernel: the frame the odd passes of a batch write
+    size_t batchScratchBytes = 0;
     void* present = nullptr;                    // PTPresentToHost staging frame
     size_t presentBytes = 0;
     DScene scene = {};
@@ -375,7 +377,8 @@ int effective_schedule(const PTContext* c)
     return (c->nodes.used <= 80u * 16u && !c->scene.hasTlas) ? 0 : 1;
 }
 
-int render_to(PTContext* c, const PTFrameParams* hostParams, float4* dOut, const float4* dAcc)
+// `batch`: the passes a launch sequence renders together (count >= 1; batch.seedRoot[0] / currentSample[0] = those of *hostParams)
+int render_to(PTContext* c, const PTFrameParams* hostParams, float4* dOut, const float4* dAcc, const PTBatch* hostBatch = nullptr)
 {
     if (!c) return fail(PT_ERR_INVALID_ARG, "ctx == NULL");
     RoctxRange range("PT pass (enqueue)");
@@ -384,6 +387,9 @@ int render_to(PTContext* c, const PTFrameParams* hostParams, float4* dOut, const
     if (rc) return rc;
     const PTFrameParams* p = &params;
     if ((rc = validate_params(p))) return rc;
+    PTBatch batch = {};
+    if (hostBatch) batch = *hostBatch;
+    else { batch.count = 1u; batch.seedRoot[0] = p->RngSeedRoot; batch.currentSample[0] = p->CurrentSample; }
     if (!c->hasScene) return fail(PT_ERR_NO_SCENE, "PTSetScene has not been called");
     if (!dOut) return fail(PT_ERR_INVALID_ARG, "output buffer == NULL");
     if (p->CurrentSample > 0 && !dAcc) return fail(PT_ERR_INVALID_ARG, "CurrentSample > 0 needs an accumulated frame");
@@ -414,13 +420,17 @@ int render_to(PTContext* c, const PTFrameParams* hostParams, float4* dOut, const
         // every set IN USE is carved on the FIRST pass of a frame size (a no-op afterwards): a caller that times passes after a
         // short warm-up must not find the allocation of sets it has not reached yet inside its timed region.  Sets beyond
         // PTSetPassesInFlight are never allocated (0.6 GB each at 1080p).
-        for (uint32_t k = 0; k < c->numSets; ++k)
-            if ((rc = ensure_wavefront(c, c->sets[k], pt_num_slots(tm), (uint32_t)(maxIt > 65536u ? 65536u : maxIt)))) return rc;
+        const uint32_t slotsPerPass = pt_num_slots(tm);
+        if ((uint64_t)slotsPerPass * batch.count > 0x3FFFFFFFull) return fail(PT_ERR_UNSUPPORTED, "batch too large: passes x owned pixels exceeds 2^30 slots");
+        for (uint32_t k = 0; k < c->numSets; ++k) {
+            if ((rc = ensure_wavefront(c, c->sets[k], slotsPerPass * batch.count, (uint32_t)(maxIt > 65536u ? 65536u : maxIt)))) return rc;
+            c->sets[k].wf.slotsPerPass = slotsPerPass;
+        }
         // the launch chain runs on the set's own stream; only its resolve (which reads `accumulated` and writes `output`)
         // is ordered after what the caller has enqueued on the context stream so far, the previous pass included
         HIP_TRY(hipEventRecord(set.callEv, c->stream));
         if (c->profiling) HIP_TRY(hipEventRecord(ep.start, set.stream));
-        HIP_TRY(pt_launch_wavefront(c->scene, *p, dAcc, dOut, tm, set.wf, c->dStats, c->statsLevel > 0, set.stream, set.callEv,
+        HIP_TRY(pt_launch_wavefront(c->scene, *p, batch, dAcc, dOut, tm, set.wf, c->dStats, c->statsLevel > 0, set.stream, set.callEv,
                                     c->world > 1, &launches, schedule == 4 ? 4 : (schedule == 1 ? 2 : (schedule == 2 ? 1 : 0)), c->wfIterations));
         if (c->profiling) HIP_TRY(hipEventRecord(ep.stop, set.stream));
         HIP_TRY(hipEventRecord(set.done, set.stream));
@@ -429,6 +439,7 @@ int render_to(PTContext* c, const PTFrameParams* hostParams, float4* dOut, const
     }
     case 0:
     default:
+        if (batch.count != 1u) return fail(PT_ERR_UNSUPPORTED, "internal: the megakernel renders one pass per launch");
         // pixels this context does not own must read as exact zeros (sum over ranks == single-GPU frame)
         if (c->world > 1)
             HIP_TRY(hipMemsetAsync(dOut, 0, (size_t)p->OutputWidth * p->OutputHeight * sizeof(float4), c->stream));
@@ -482,6 +493,7 @@ PT_API int PTDestroy(PTContext* c)
     for (int i = 0; i < 2; i++) if (c->frames[i]) hipFree(c->frames[i]);
     if (c->dStats) hipFree(c->dStats);
     if (c->present) hipFree(c->present);
+    if (c->batchScratch) hipFree(c->batchScratch);
     for (auto& set : c->sets) {
         if (set.stream) { hipStreamSynchronize(set.stream); hipStreamDestroy(set.stream); }
         if (set.arena) hipFree(set.arena);
@@ -621,6 +633,55 @@ PT_API int PTResetFrames(PTContext* c) { if (!c) return fail(PT_ERR_INVALID_ARG,
 PT_API int PTRenderPassTo(PTContext* c, const PTFrameParams* p, void* dOutput, const void* dAccumulated)
 {
     return render_to(c, p, (float4*)dOutput, (const float4*)dAccumulated);
+}
+
+PT_API int PTRenderPassBatchTo(PTContext* c, const PTFrameParams* hostParams, int count, void* dOutput, const void* dAccumulated)
+{
+    if (!c || !hostParams) return fail(PT_ERR_INVALID_ARG, "ctx/params == NULL");
+    if (count < 1 || count > PT_MAX_BATCH) return fail(PT_ERR_INVALID_ARG, "count outside 1.." + std::to_string(PT_MAX_BATCH));
+    // the host's array has the stride of ITS header (structSize of the first element)
+    const uint32_t stride = hostParams->structSize;
+    if (stride < PT_FRAME_PARAMS_MIN_SIZE || stride > 4096u) return fail(PT_ERR_INVALID_ARG, "PTFrameParams.structSize is not set");
+    PTFrameParams first, other;
+    int rc = import_params(hostParams, first);
+    if (rc) return rc;
+    PTBatch batch = {};
+    batch.count = (uint32_t)count;
+    for (int j = 0; j < count; ++j) {
+        const PTFrameParams* hp = (const PTFrameParams*)((const char*)hostParams + (size_t)j * stride);
+        if (hp->structSize != stride) return fail(PT_ERR_INVALID_ARG, "every PTFrameParams of a batch must carry the same structSize");
+        if ((rc = import_params(hp, other))) return rc;
+        batch.seedRoot[j] = other.RngSeedRoot;
+        batch.currentSample[j] = other.CurrentSample;
+        other.RngSeedRoot = first.RngSeedRoot;
+        other.CurrentSample = first.CurrentSample;
+        if (memcmp(&other, &first, sizeof(first)) != 0)
+            return fail(PT_ERR_INVALID_ARG, "the passes of a batch may differ in RngSeedRoot and CurrentSample only (pass " + std::to_string(j) + " differs elsewhere)");
+    }
+    if (count == 1) return render_to(c, hostParams, (float4*)dOutput, (const float4*)dAccumulated);
+    if (effective_schedule(c) == 0) {
+        // the megakernel writes pixels itself: run the passes one by one, ping-ponging between dOutput and a scratch frame so that the
+        // last pass lands in dOutput
+        if ((rc = validate_params(&first))) return rc;
+        HIP_TRY(hipSetDevice(c->device));
+        const size_t bytes = (size_t)first.OutputWidth * first.OutputHeight * sizeof(float4);
+        if (c->batchScratchBytes < bytes) {
+            if (c->batchScratch) { HIP_TRY(hipStreamSynchronize(c->stream)); hipFree(c->batchScratch); c->batchScratch = nullptr; c->batchScratchBytes = 0; }
+            HIP_TRY(hipMalloc(&c->batchScratch, bytes));
+            c->batchScratchBytes = bytes;
+        }
+        const float4* acc = (const float4*)dAccumulated;
+        for (int j = 0; j < count; ++j) {
+            PTFrameParams pj = first;
+            pj.RngSeedRoot = batch.seedRoot[j];
+            pj.CurrentSample = batch.currentSample[j];
+            float4* out = ((count - 1 - j) & 1) ? (float4*)c->batchScratch : (float4*)dOutput;
+            if ((rc = render_to(c, &pj, out, acc))) return rc;
+            acc = out;
+        }
+        return PT_OK;
+    }
+    return render_to(c, hostParams, (float4*)dOutput, (const float4*)dAccumulated, &batch);
 }
 
 PT_API int PTSynchronize(PTContext* c)

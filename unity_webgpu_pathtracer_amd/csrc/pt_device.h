@@ -1330,9 +1330,11 @@ PT_DEV void path_start_sample(const PTFrameParams& P, uint32_t pixelX, uint32_t 
     r.state = PS_TRACE;
 }
 
-PT_DEV void path_init(const PTFrameParams& P, uint32_t pixelX, uint32_t pixelY, uint32_t pixelIndex, PathRegs& r, Counters& cn)
+// seedRoot / currentSample: RngSeedRoot and CurrentSample of the pass the path belongs to (P's own, or those of pass j of a batch)
+PT_DEV void path_init(const PTFrameParams& P, uint32_t seedRoot, uint32_t currentSample, uint32_t pixelX, uint32_t pixelY, uint32_t pixelIndex,
+                      PathRegs& r, Counters& cn)
 {
-    r.rng = pixelIndex * (P.CurrentSample + 1u) + P.RngSeedRoot;         // PathTracer.compute:60
+    r.rng = pixelIndex * (currentSample + 1u) + seedRoot;                // PathTracer.compute:60
     r.sampleIdx = 0u;
     r.color = mk3(0.0f);
     r.env.valid = 0u; r.light.valid = 0u;

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256, PT_MK_MIN_WAVES) void pt_megakernel(DScene S, 
     PathRegs r;
     r.ro = mk3(0.0f); r.rd = mk3(0.0f, 0.0f, 1.0f);
     r.state = PS_DONE;
-    if (inside) path_init(P, pixelX, pixelY, pixelIndex, r, cn);
+    if (inside) path_init(P, P.RngSeedRoot, P.CurrentSample, pixelX, pixelY, pixelIndex, r, cn);
 
     while (r.state != PS_DONE) {
         // ---- traversal pass (<= 3 rays per lane); ray slots rotate through registers: slot 0 is traced, slots 1, 2 move down

@@ -95,6 +95,7 @@ struct PTWfBuffers {
     uint32_t* chunkHeads;       // [8 shards x 32 words]: work counters of the persistent trace kernel, one 128-B line each
     unsigned long long* statRows;   // [numStatRows][16]
     uint32_t numSlots, numStatRows, maxIterations;
+    uint32_t slotsPerPass;      // numSlots = passes of the batch x slotsPerPass; slot s belongs to pass s / slotsPerPass, pixel slot s % slotsPerPass
     uint32_t residentWaves;     // waves the device holds at the trace kernel's occupancy (CUs x 4 SIMDs x 8)
 };
 
@@ -114,7 +115,23 @@ inline uint32_t pt_wf_max_trace_waves(uint32_t numSlots, uint32_t residentWaves)
     return wide > persist ? wide : persist;
 }
 
-hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const float4* accumulated, float4* output,
+// A BATCH of progressive passes rendered by ONE launch sequence (PTRenderPassBatchTo): the passes differ only in RngSeedRoot and
+// CurrentSample, their paths are independent (the running mean of PathTracer.compute:89-98 only meets them in the resolve kernel,
+// which applies the passes in order), so a launch covers count x slotsPerPass slots.
+#define PT_MAX_BATCH 8
+struct PTBatch {
+    uint32_t count;
+    uint32_t seedRoot[PT_MAX_BATCH];
+    uint32_t currentSample[PT_MAX_BATCH];
+};
+__host__ __device__ inline void pt_batch_pick(const PTBatch& b, uint32_t j, uint32_t& seedRoot, uint32_t& currentSample)
+{
+    seedRoot = b.seedRoot[0]; currentSample = b.currentSample[0];
+#pragma unroll
+    for (uint32_t k = 1; k < PT_MAX_BATCH; ++k) if (j == k) { seedRoot = b.seedRoot[k]; currentSample = b.currentSample[k]; }
+}
+
+hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const PTBatch& batch, const float4* accumulated, float4* output,
                                const PTTileMap& tm, const PTWfBuffers& B, unsigned long long* gstats, bool fullStats,
                                hipStream_t stream, hipEvent_t orderAfter, bool zeroOutputFirst,
                                uint32_t* launchesOut, int traceVariant, uint32_t iterationsOverride);

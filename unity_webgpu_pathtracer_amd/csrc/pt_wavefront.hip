@@ -108,17 +108,27 @@ PT_DEV void flush_counters(const Counters& cn, unsigned long long* rows, uint32_
 // ------------------------------------------------------------------------------------------
 // init: every owned pixel starts its first sample (camera ray in the slot, state = TRACE)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pt_wf_init(PTFrameParams P, PTTileMap tm, PTWfBuffers B)
+// the pixel slot and the pass (of a batch) a slot belongs to
+PT_DEV uint32_t pixel_slot_of(const PTWfBuffers& B, uint32_t slot, uint32_t& pass)
+{
+    pass = 0u;
+    if (slot >= B.slotsPerPass) { pass = slot / B.slotsPerPass; slot -= pass * B.slotsPerPass; }
+    return slot;
+}
+
+__global__ __launch_bounds__(256) void pt_wf_init(PTFrameParams P, PTBatch batch, PTTileMap tm, PTWfBuffers B)
 {
     const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
     if (blockIdx.x == 0u && threadIdx.x < PT_WF_SHARDS) B.chunkHeads[threadIdx.x * 32u] = 0u;
     if (slot >= B.numSlots) return;
-    uint32_t px, py;
+    uint32_t px, py, pass;
     Counters cn = {};
-    if (!pt_slot_to_pixel(tm, slot, px, py)) B.flags[slot] = PS_DONE;
+    if (!pt_slot_to_pixel(tm, pixel_slot_of(B, slot, pass), px, py)) B.flags[slot] = PS_DONE;
     else {
         PathRegs r;
-        path_init(P, px, py, py * P.OutputWidth + px, r, cn);
+        uint32_t seedRoot, currentSample;
+        pt_batch_pick(batch, pass, seedRoot, currentSample);
+        path_init(P, seedRoot, currentSample, px, py, py * P.OutputWidth + px, r, cn);
         store_path(B, slot, r, false);
     }
     // every lane of the wave takes part in the reduction (a lane that had returned would be read as garbage)
@@ -858,8 +868,8 @@ template <bool STATS, bool PIXSUM = false>
 PT_DEV bool shade_slot(const DScene& S, const PTFrameParams& P, const PTTileMap& tm, const PTWfBuffers& B, uint32_t slot, uint32_t pixelSlot,
                        uint32_t f, Counters& cn)
 {
-    uint32_t px, py;
-    pt_slot_to_pixel(tm, pixelSlot, px, py);
+    uint32_t px, py, pass;
+    pt_slot_to_pixel(tm, pixel_slot_of(B, pixelSlot, pass), px, py);
     uint32_t rng = B.rng[slot];
     float4 qro = B.ray[0][2u * slot], qrd = B.ray[0][2u * slot + 1u], qrad = B.rad[slot], qthr = B.thr[slot], qcol = B.color[slot];
     float4 qenvC = B.envC[slot], qlightC = B.lightC[slot], qpthr = B.pthr[slot], qhit = B.hit[slot];
@@ -1005,7 +1015,7 @@ PT_DEV void counters_to_lds(const Counters& cn, volatile uint32_t* tot, uint32_t
 }
 
 template <bool STATS>
-__global__ __launch_bounds__(64, PT_WF_FUSED_WAVES) void pt_wf_fused(DScene S, PTFrameParams P, PTTileMap tm, PTWfBuffers B)
+__global__ __launch_bounds__(64, PT_WF_FUSED_WAVES) void pt_wf_fused(DScene S, PTFrameParams P, PTBatch batch, PTTileMap tm, PTWfBuffers B)
 {
     constexpr uint32_t K = PT_WF_FUSED_GROUPS;
     constexpr uint32_t kSusp = PT_WF_SUSPEND ? PT_WF_SUSPEND : 1u;
@@ -1063,10 +1073,12 @@ __global__ __launch_bounds__(64, PT_WF_FUSED_WAVES) void pt_wf_fused(DScene S, P
                 Counters cn = {};
                 if (mine == PT_WF_NO_PIXEL) {
                     const uint32_t slot = base + rank_below(E);
-                    uint32_t px, py;
-                    if (slot < B.numSlots && pt_slot_to_pixel(tm, slot, px, py)) {      // (slots of partially covered edge tiles have no pixel)
+                    uint32_t px, py, pass;
+                    if (slot < B.numSlots && pt_slot_to_pixel(tm, pixel_slot_of(B, slot, pass), px, py)) {      // (slots of partially covered edge tiles have no pixel)
                         PathRegs r;
-                        path_init(P, px, py, py * P.OutputWidth + px, r, cn);
+                        uint32_t seedRoot, currentSample;
+                        pt_batch_pick(batch, pass, seedRoot, currentSample);
+                        path_init(P, seedRoot, currentSample, px, py, py * P.OutputWidth + px, r, cn);
                         store_path(B, ctx, r, false);
                         mine = slot;
                         pix[k * 64u + lane] = slot;
@@ -1283,8 +1295,8 @@ __global__ __launch_bounds__(256, 2) void pt_wf_cleanup(DScene S, PTFrameParams 
     const uint32_t f = B.flags[slot];
     if (__any(fl_state(f) != PS_DONE)) {
         if (fl_state(f) != PS_DONE) {
-            uint32_t px, py;
-            pt_slot_to_pixel(tm, slot, px, py);
+            uint32_t px, py, pass;
+            pt_slot_to_pixel(tm, pixel_slot_of(B, slot, pass), px, py);
             PathRegs r;
             load_path(B, slot, f, r);
             if (r.hasPending) {
@@ -1327,29 +1339,38 @@ __global__ __launch_bounds__(256, 2) void pt_wf_cleanup(DScene S, PTFrameParams 
     flush_counters<STATS>(cn, B.statRows, blockIdx.x * 4u + (threadIdx.x >> 6), threadIdx.x & 63u);
 }
 
-// resolve: the pixel write of PathTracer.compute:89-98, applied to every slot's sample sum
-__global__ __launch_bounds__(256) void pt_wf_resolve(PTFrameParams P, PTTileMap tm, PTWfBuffers B, const float4* __restrict__ sums,
+// resolve: the pixel write of PathTracer.compute:89-98, applied to every pixel's sample sum -- for a batch, once per pass and in
+// pass order, each pass reading what the previous one would have written (the intermediate frames are never stored; the running
+// mean is the same chain of fp32 operations)
+__global__ __launch_bounds__(256) void pt_wf_resolve(PTFrameParams P, PTBatch batch, PTTileMap tm, PTWfBuffers B, const float4* __restrict__ sums,
                                                      const float4* __restrict__ accumulated, float4* __restrict__ output)
 {
     const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
     uint32_t px, py;
     Counters cn = {};
-    if (slot < B.numSlots && pt_slot_to_pixel(tm, slot, px, py)) {
+    if (slot < B.slotsPerPass && pt_slot_to_pixel(tm, slot, px, py)) {
         const uint32_t pixelIndex = py * P.OutputWidth + px;
         const uint32_t numSamples = P.SamplesPerPass > 1 ? (uint32_t)P.SamplesPerPass : 1u;
         const float fSamples = (float)numSamples;
-        const v3 color = xyz(sums[slot]);                       // per-pixel sample sum: B.color (schedules 1-3) or B.pixsum (schedule 4)
-        v3 acc;
-        if (P.CurrentSample > 0u) {
-            float4 a = accumulated[pixelIndex];
-            cn.pixelsRead++;
-            float cs = (float)P.CurrentSample;
-            acc = (color + mk3(a.x, a.y, a.z) * cs) / (cs + fSamples);
-        } else {
-            acc = color / fSamples;
+        v3 acc = mk3(0.0f);
+        for (uint32_t j = 0; j < batch.count; ++j) {
+            uint32_t seedRoot, currentSample;
+            pt_batch_pick(batch, j, seedRoot, currentSample);
+            const v3 color = xyz(sums[(size_t)j * B.slotsPerPass + slot]);      // per-pixel sample sum: B.color (schedules 1-3) or B.pixsum (schedule 4)
+            if (currentSample > 0u) {
+                if (j == 0u) {
+                    const float4 a = accumulated[pixelIndex];
+                    acc = mk3(a.x, a.y, a.z);
+                }
+                cn.pixelsRead++;
+                const float cs = (float)currentSample;
+                acc = (color + acc * cs) / (cs + fSamples);
+            } else {
+                acc = color / fSamples;
+            }
+            cn.pixelsWritten++;
         }
         output[pixelIndex] = make_float4(acc.x, acc.y, acc.z, 1.0f);
-        cn.pixelsWritten++;
     }
     flush_counters<false>(cn, B.statRows, blockIdx.x * 4u + (threadIdx.x >> 6), threadIdx.x & 63u);
 }
@@ -1385,12 +1406,12 @@ __global__ __launch_bounds__(256) void pt_wf_fold_rows(unsigned long long* rows,
 // One pass = a fixed sequence of launches on `stream`, no host synchronisation (see the file header).
 // `orderAfter` (may be null) is the event of the previous pass's resolve: this pass's resolve reads that pass's output as
 // AccumulatedOutput and, with ping-pong frames, overwrites the frame that resolve was still reading.
-hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const float4* accumulated, float4* output,
+hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const PTBatch& batch, const float4* accumulated, float4* output,
                                const PTTileMap& tm, const PTWfBuffers& B, unsigned long long* gstats, bool fullStats,
                                hipStream_t stream, hipEvent_t orderAfter, bool zeroOutputFirst,
                                uint32_t* launchesOut, int traceVariant, uint32_t iterationsOverride)
 {
-    const uint32_t nb = B.numSlots >> 8;
+    const uint32_t nb = B.numSlots >> 8, nbPass = B.slotsPerPass >> 8;
     uint32_t launches = 0;
     hipError_t e;
     const bool tlas = S.hasTlas != 0u;
@@ -1404,19 +1425,19 @@ hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const fl
         uint32_t waves = B.residentWaves / 8u * (uint32_t)PT_WF_FUSED_WAVES;          // CUs x 4 SIMDs x waves per SIMD
         if (waves > maxWaves) waves = maxWaves;
         if (waves == 0u) waves = 1u;
-        if (fullStats) hipLaunchKernelGGL(pt_wf_fused<true>, dim3(waves), dim3(64), 0, stream, S, P, tm, B);
-        else hipLaunchKernelGGL(pt_wf_fused<false>, dim3(waves), dim3(64), 0, stream, S, P, tm, B);
+        if (fullStats) hipLaunchKernelGGL(pt_wf_fused<true>, dim3(waves), dim3(64), 0, stream, S, P, batch, tm, B);
+        else hipLaunchKernelGGL(pt_wf_fused<false>, dim3(waves), dim3(64), 0, stream, S, P, batch, tm, B);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if (orderAfter && (e = hipStreamWaitEvent(stream, orderAfter, 0)) != hipSuccess) return e;
         if (zeroOutputFirst &&
             (e = hipMemsetAsync(output, 0, (size_t)P.OutputWidth * P.OutputHeight * sizeof(float4), stream)) != hipSuccess) return e;
-        hipLaunchKernelGGL(pt_wf_resolve, dim3(nb), dim3(256), 0, stream, P, tm, B, (const float4*)B.pixsum, accumulated, output);
+        hipLaunchKernelGGL(pt_wf_resolve, dim3(nbPass), dim3(256), 0, stream, P, batch, tm, B, (const float4*)B.pixsum, accumulated, output);
         hipLaunchKernelGGL(pt_wf_fold_rows, dim3(256), dim3(256), 0, stream, B.statRows, B.numStatRows, gstats);
         if (launchesOut) *launchesOut = 3u;
         return hipGetLastError();
     }
     if ((e = hipMemsetAsync(B.aliveFlags, 0, sizeof(uint32_t) * B.maxIterations * PT_WF_ALIVE_SHARDS, stream)) != hipSuccess) return e;
-    hipLaunchKernelGGL(pt_wf_init, dim3(nb), dim3(256), 0, stream, P, tm, B);
+    hipLaunchKernelGGL(pt_wf_init, dim3(nb), dim3(256), 0, stream, P, batch, tm, B);
     launches++;
     const uint32_t spp = P.SamplesPerPass > 1 ? (uint32_t)P.SamplesPerPass : 1u;
     const uint32_t bounces = P.MaxRayBounces > 1u ? P.MaxRayBounces : 1u;
@@ -1477,7 +1498,7 @@ hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const fl
     if (orderAfter && (e = hipStreamWaitEvent(stream, orderAfter, 0)) != hipSuccess) return e;
     if (zeroOutputFirst &&
         (e = hipMemsetAsync(output, 0, (size_t)P.OutputWidth * P.OutputHeight * sizeof(float4), stream)) != hipSuccess) return e;
-    hipLaunchKernelGGL(pt_wf_resolve, dim3(nb), dim3(256), 0, stream, P, tm, B, (const float4*)B.color, accumulated, output);
+    hipLaunchKernelGGL(pt_wf_resolve, dim3(nbPass), dim3(256), 0, stream, P, batch, tm, B, (const float4*)B.color, accumulated, output);
     hipLaunchKernelGGL(pt_wf_fold_rows, dim3(256), dim3(256), 0, stream, B.statRows, B.numStatRows, gstats);
     launches += 3;
     if (launchesOut) *launchesOut = launches;

@@ -178,6 +178,11 @@ class PathTracer:
     def render_pass_to(self, p: abi.PTFrameParams, d_output: int, d_accumulated: int = 0):
         plugin.check(self.lib.PTRenderPassTo(self.ctx, C.byref(p), C.c_void_p(d_output), C.c_void_p(d_accumulated or None)))
 
+    def render_batch_to(self, params, d_output: int, d_accumulated: int = 0):
+        """PTRenderPassBatchTo: `params` = list of PTFrameParams (1..8 passes differing in RngSeedRoot / CurrentSample only)."""
+        arr = (abi.PTFrameParams * len(params))(*params)
+        plugin.check(self.lib.PTRenderPassBatchTo(self.ctx, arr, len(params), C.c_void_p(d_output), C.c_void_p(d_accumulated or None)))
+
     def flip(self):
         plugin.check(self.lib.PTFlipFrames(self.ctx))
 

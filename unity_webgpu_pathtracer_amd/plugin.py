@@ -60,6 +60,7 @@ def load_library():
         "PTRenderPass": (i32, [vp, C.POINTER(abi.PTFrameParams)]),
         "PTFlipFrames": (i32, [vp]), "PTResetFrames": (i32, [vp]),
         "PTRenderPassTo": (i32, [vp, C.POINTER(abi.PTFrameParams), vp, vp]),
+        "PTRenderPassBatchTo": (i32, [vp, C.POINTER(abi.PTFrameParams), i32, vp, vp]),
         "PTSynchronize": (i32, [vp]), "PTReadback": (i32, [vp, vp, C.c_uint64]),
         "PTGetFramePointer": (vp, [vp, i32]), "PTGetStream": (vp, [vp]),
         "PTSetStatsLevel": (i32, [vp, i32]), "PTGetStats": (i32, [vp, C.POINTER(abi.PTStats)]), "PTResetStats": (i32, [vp]),
@@ -93,7 +94,7 @@ EXPORTED_SYMBOLS = [
     "PTBuildBVHDevice", "PTGetBVHBuildError", "PTGetBVHBuildMs",
     "BuildTLAS", "DestroyTLAS", "IsTLASReady", "GetTLASNodesSize", "GetTLASData",
     "PTCreate", "PTDestroy", "PTSetScene", "PTSetTileOwnership", "PTRenderPass", "PTFlipFrames", "PTResetFrames",
-    "PTRenderPassTo", "PTSynchronize", "PTReadback", "PTGetFramePointer", "PTGetStream", "PTSetStatsLevel", "PTGetStats",
+    "PTRenderPassTo", "PTRenderPassBatchTo", "PTSynchronize", "PTReadback", "PTGetFramePointer", "PTGetStream", "PTSetStatsLevel", "PTGetStats",
     "PTResetStats", "PTSetProfiling", "PTGetTimings", "PTResetTimings", "PTProcessMeshes", "PTCopyTextureData", "PTPresent", "PTPresentToHost", "PTSetSchedule", "PTGetSchedule", "PTSetWavefrontIterations", "PTSetPassesInFlight", "PTGetPassesInFlight",
     "PTGetOwnedTileSlots", "PTPackOwnedTiles", "PTUnpackTiles", "PTCreateMulti", "PTGroupDestroy", "PTGroupSize", "PTGroupGetContext",
     "PTGroupSetScene", "PTGroupRenderPass", "PTGroupFlipFrames", "PTGroupResetFrames", "PTGroupSynchronize", "PTGroupReadback",
