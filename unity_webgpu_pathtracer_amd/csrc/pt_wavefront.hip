@@ -503,6 +503,13 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(
 #define PT_WF_TLAS_LDS_STACK 8u
 #endif
 
+#ifndef PT_WF_TLAS_STEPS
+#define PT_WF_TLAS_STEPS 0xFFFFFFFFu // TLAS-walk steps a lane between instances takes per wave iteration (0xFFFFFFFF: until it is inside the next instance).
+                                     // 200-instance scene, 1080p / 8 spp: unbounded 2,076 Mrays/s, 1 step 1,971, 2 steps 1,889 (round 3)
+#endif
+#ifndef PT_WF_TLAS_QUORUM
+#define PT_WF_TLAS_QUORUM 0u         // > 0: the TLAS-walk block runs when that many lanes want it, or when no lane is inside an instance (8: 1,920, 16: 1,892)
+#endif
 #ifndef PT_WF_TLAS_MIN_WAVES
 #define PT_WF_TLAS_MIN_WAVES 6      // 80 VGPRs, no scratch (without the SLP vectorizer); 5 waves: -3 %
 #endif
@@ -593,10 +600,21 @@ __global__ __launch_bounds__(64, PT_WF_TLAS_MIN_WAVES) void pt_wf_trace_refill_t
         if (nIdle == 64u) break;
         const uint32_t stopAt = cursor < nItems ? PT_WF_REFILL : 64u;
         do {
-            // ---- (rare) a lane that is between instances: instance epilogue is done; walk the TLAS to the next instance
-            if (have && !inBlas) {
+            // ---- a lane that is between instances (its instance epilogue is done) walks the TLAS to the next instance whose box it hits.
+            //      Per ray of the 200-instance scene: 13.0 TLAS nodes + 5.9 instance entries + 9.6 BLAS nodes + 3.0 triangles = 37
+            //      DEPENDENT memory round trips against 18.6 for the same geometry baked flat -- the 1.9x in time.  Rescheduling the
+            //      steps does not shorten that chain: one TLAS step per wave iteration (PT_WF_TLAS_STEPS = 1), a quorum for this block
+            //      and triangle parking (round 2) all measured slower than walking until the lane is inside its next instance.
+            const bool walkT = have && !inBlas;
+#if PT_WF_TLAS_QUORUM > 0
+            const uint32_t nWalk = (uint32_t)__popcll(__ballot(walkT)), nIn = (uint32_t)__popcll(__ballot(have && inBlas));
+            const bool runWalk = nWalk >= PT_WF_TLAS_QUORUM || nIn == 0u;
+#else
+            const bool runWalk = true;
+#endif
+            if (walkT && runWalk) {
                 bool finished = false;
-                while (true) {
+                for (uint32_t stepT = 0; stepT < PT_WF_TLAS_STEPS; ++stepT) {
                     if (instLeft > 0u) {
                         // enter the next instance of the current TLAS leaf (tlas.hlsl:129-147)
                         instIndex = pt_asuint(T[S.tlasIndexOffset + nextInst]);
