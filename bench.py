@@ -370,6 +370,23 @@ def main():
                             "peak_source": rec.get("issue_peak_source", "")}
             except Exception:
                 valu = None
+        # the committed rocprofv3 summary of THIS command (profiles/collect.sh): span-based time per pass with the passes pipelined
+        # as here, and per-kernel durations from a second trace with one pass in flight
+        profile = None
+        try:
+            import glob
+            pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc.json")))[-1]
+            rec = json.load(open(pj))
+            if rec.get("workload") == args.workload and "trace" in rec:
+                ser = rec.get("serialised", {})
+                profile = {"source": os.path.relpath(pj, ROOT) + " (profiles/collect.sh; not this run)",
+                           "pipelined_ms_per_pass": round(rec["trace"].get("steady_ms_per_pass", 0.0), 4),
+                           "pipelined_mean_kernels_in_flight": round(rec["trace"].get("mean_kernels_in_flight", 0.0), 2),
+                           "serialised_ms_per_pass": round(ser.get("trace", {}).get("steady_ms_per_pass", 0.0), 4),
+                           "serialised_kernel_ms_per_pass": {k: round(v["total_per_pass"], 4) for k, v in ser.get("kernel_ms", {}).items() if v["total_per_pass"] >= 0.01},
+                           "lane_utilisation": {k: round(v, 3) for k, v in rec.get("pmc", {}).get("lane_utilisation", {}).items() if "trace" in k or "shade" in k}}
+        except Exception:
+            profile = None
         out = {
             "metric": "Mrays/s at 1920x1080, 8 spp", "value": round(main_res["mrays_per_s"], 3), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(main_res["ms_per_step"], 4),
@@ -390,6 +407,11 @@ def main():
                          "counters_per_launch": {k: round(v) for k, v in main_res["counters_per_launch"].items()},
                          "max_stack_depth": main_res["max_stack_depth"],
                          "valu_issue": valu,
+                         "binding_roof": ({"name": "valu_issue", "frac": valu["frac"],
+                                           "why": "the scene (148 MB) is Infinity-Cache resident, so the 8 TB/s HBM roof above is nominal (SURVEY.md 8d defines it); "
+                                                  "what the pass saturates first is VALU issue under divergence: wave instructions of a pass / measured issue peak"}
+                                          if valu else None),
+                         "profile": profile,
                          "note": "rank-0 kernels; achieved = algorithmic bytes of a pass / its device time (HIP events on the context stream, passes overlap); "
                                  "the scene is Infinity-Cache resident, so HBM is the nominal roof only: the pass is bound by VALU issue at 40-55 % lane "
                                  "utilisation (valu_issue.frac), with the texture-data path ~70 % busy (DESIGN.md 5.4)"},

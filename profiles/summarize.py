@@ -54,6 +54,23 @@ def per_pass(rows, value_of):
     return [total / n_pass] * n_pass, {k: v / n_pass for k, v in per_kernel.items()}
 
 
+def regime_summary(rows, regime, warmup=5):
+    """Span-based time per pass of a kernel trace: a pass is complete when its pt_wf_resolve (or pt_megakernel) ends; the steady
+    figure is (end of the last pass - end of the last WARM-UP pass) / timed passes -- what bench.py's HIP events measure.  Also the
+    sum of kernel durations per pass and the mean number of kernels running at once (sum / span)."""
+    ends = sorted(int(r["End_Timestamp"]) for r in rows if "pt_wf_resolve" in r["Kernel_Name"] or "pt_megakernel" in r["Kernel_Name"])
+    t0 = min(int(r["Start_Timestamp"]) for r in rows)
+    t1 = max(int(r["End_Timestamp"]) for r in rows)
+    busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows)
+    n = len(ends)
+    res = {"regime": regime, "passes": n, "span_ms": (t1 - t0) / 1e6, "sum_of_kernel_ms_per_pass": busy / 1e6 / max(1, n),
+           "mean_kernels_in_flight": busy / max(1, t1 - t0)}
+    if n > warmup:
+        res["steady_ms_per_pass"] = (ends[-1] - ends[warmup - 1]) / 1e6 / (n - warmup)
+        res["steady_note"] = f"(end of pass {n} - end of warm-up pass {warmup}) / {n - warmup} timed passes"
+    return {"trace": res}
+
+
 def newest(pattern):
     """gpurun merges every call's files into gpurun_out/: several runs of one pass may lie side by side -- take the latest."""
     return sorted(glob.glob(pattern), key=os.path.getmtime, reverse=True)
@@ -80,9 +97,23 @@ def main():
         out["resources"] = res
         t0 = min(int(r["Start_Timestamp"]) for r in rows)
         t1 = max(int(r["End_Timestamp"]) for r in rows)
-        n_pass = sum(1 for r in rows if "pt_wf_init" in r["Kernel_Name"] or "pt_megakernel" in r["Kernel_Name"])
+        n_pass = sum(1 for r in rows if "pt_wf_init" in r["Kernel_Name"] or "pt_megakernel" in r["Kernel_Name"] or "pt_wf_fused" in r["Kernel_Name"])
         out["passes"] = n_pass
         out["span_ms_per_pass"] = (t1 - t0) / 1e6 / max(1, n_pass)
+        out.update(regime_summary(rows, "pipelined: the command bench.py's default run times (--steps 20 --warmup 5, the library's default number of passes in flight)"))
+    serial = newest(os.path.join(base, f"{tag}_serial", "*", "*_kernel_trace.csv"))
+    if serial:
+        rows = [r for r in csv.DictReader(open(serial[0])) if "pt_" in r["Kernel_Name"]]
+        ser = regime_summary(rows, "serialised: the same command with --passes-in-flight 1 (the kernels of a pass run back to back, nothing overlaps them): honest per-kernel durations")
+        per = {}
+        for r in rows:
+            per.setdefault(short(r["Kernel_Name"]), []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+        n = max(1, ser["trace"]["passes"])
+        ser["kernel_ms"] = {k: {"calls_per_pass": len(v) / n, "mean": sum(v) / len(v), "total_per_pass": sum(v) / n} for k, v in per.items()}
+        out["serialised"] = ser
+        st = newest(os.path.join(base, f"{tag}_serial", "*", "*_kernel_stats.csv"))
+        if st:
+            shutil.copy(st[0], os.path.join(ROOT, "profiles", f"{tag}_kernel_stats_serialised.csv"))
     pmc = {}
     for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         f = newest(os.path.join(base, f"{tag}_{kind}", "*", "*_counter_collection.csv"))
@@ -126,6 +157,16 @@ def main():
                         "frac_active_valu": v.get("SQ_ACTIVE_INST_VALU", 0.0) / wc, "frac_active_any": v.get("SQ_ACTIVE_INST_ANY", 0.0) / wc,
                         "frac_wait_issue": v.get("SQ_WAIT_INST_ANY", 0.0) / wc, "frac_wait_memory": v.get("SQ_WAIT_ANY", 0.0) / wc}
         pmc["wave_cycle_breakdown"] = {"by_kernel": waits, "note": "SQ_* in quad-cycles; ACTIVE_INST_ANY + WAIT_INST_ANY + WAIT_ANY ~ WAVE_CYCLES (profiled passes run serialised)"}
+    f = newest(os.path.join(base, f"{tag}_lane", "*", "*_counter_collection.csv"))
+    if f:
+        agg = {}
+        for r in csv.DictReader(open(f[0])):
+            if "pt_" not in r["Kernel_Name"]:
+                continue
+            agg.setdefault(short(r["Kernel_Name"]), {}).setdefault(r["Counter_Name"], 0.0)
+            agg[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
+        pmc["lane_utilisation"] = {k: v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"]) for k, v in agg.items()
+                                   if v.get("SQ_ACTIVE_INST_VALU", 0) > 0 and "SQ_THREAD_CYCLES_VALU" in v}
     # vector-memory path, L2 and dispatcher counters, summed per kernel over the profiled passes (one rocprofv3 run per block)
     mem = {}
     for name in ("ta", "td", "tcp", "tcc", "grbm", "spi"):
