@@ -50,3 +50,36 @@ def test_small_stack_build_is_bit_exact(tmp_path, oracle):
         d = st.as_dict()
         assert np.array_equal(got[name + "_stats"], np.array([d[k] for k in sorted(d)], dtype=np.uint64)), name
         assert d["maxStackDepth"] >= 2                              # deeper than the stress build's LDS part: the slab was used
+
+
+SORTED_CHILD = r'''
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from unity_webgpu_pathtracer_amd import scenes
+from unity_webgpu_pathtracer_amd.pathtracer import PathTracer
+out = {}
+for name, s, w, h, spp in (("zoo", scenes.material_zoo(), 136, 88, 3), ("tlas", scenes.instanced_scene(count=20, detail=8), 128, 72, 2)):
+    pt = PathTracer(s, width=w, height=h, samplesPerPass=spp, schedule=1)
+    pt.set_stats_level(1)
+    for k in range(2):
+        pt.OnRenderImage(0x50A7ED + k)
+    out[name] = pt.readback()
+    st = pt.stats().as_dict()
+    out[name + "_stats"] = np.array([st[k] for k in sorted(st)], dtype=np.uint64)
+    pt.close()
+np.savez(sys.argv[2], **out)
+'''
+
+
+@pytest.mark.gpu
+def test_lds_regrouped_shade_kernel_is_bit_exact(tmp_path):
+    """pt_wf_shade_sorted (PT_WF_SHADE_SORTED=1: stage 2 of path_step regrouped through LDS inside 256-slot workgroups) against the
+    default slot-order shade kernel: two progressive passes, frames and all counters identical (textures, all lobes, three light
+    types, partially covered edge blocks; HAS_TLAS)."""
+    outs = {}
+    for v in ("0", "1"):
+        out = str(tmp_path / f"sorted{v}.npz")
+        subprocess.check_call([sys.executable, "-c", SORTED_CHILD, ROOT, out], env=dict(os.environ, PT_WF_SHADE_SORTED=v), timeout=600)
+        outs[v] = np.load(out)
+    for key in outs["0"].files:
+        assert np.array_equal(outs["0"][key].view(np.uint8), outs["1"][key].view(np.uint8)), key

@@ -113,6 +113,7 @@ struct PTContext {
     uint32_t nextSet = 0;
     uint32_t numSets = 0;                       // passes in flight = state sets in use (PTSetPassesInFlight); carved on first use
     uint32_t wfIterations = 0;                  // 0 = automatic
+    uint32_t shadeSorted = PT_WF_SHADE_SORTED;  // PT_WF_SHADE_SORTED in the environment overrides (experiments)
     uint32_t tailCut = PT_WF_TAIL_CUT;          // wavefront tail cut (pt_wavefront.hip tail_cut); PT_WF_TAIL_CUT in the environment overrides (experiments)
 };
 
@@ -155,6 +156,7 @@ int ensure_wavefront(PTContext* c, PTContext::WfSet& set, uint32_t numSlots, uin
     }
     const bool needTlas = c->scene.hasTlas != 0u;
     set.wf.tailCut = c->tailCut;
+    set.wf.shadeSorted = c->shadeSorted;
     if (set.wf.flags && set.wf.numSlots == numSlots && set.wf.maxIterations >= maxIterations && (!needTlas || set.wf.tlasSpill)) return PT_OK;
     HIP_TRY(hipStreamSynchronize(set.stream));
     const size_t n = numSlots;
@@ -474,6 +476,7 @@ PT_API int PTCreate(int deviceIndex, PTContext** outCtx)
     PTContext* c = new PTContext();
     c->device = deviceIndex;
     c->numSets = default_passes_in_flight();
+    if (const char* e = getenv("PT_WF_SHADE_SORTED")) c->shadeSorted = (uint32_t)strtoul(e, nullptr, 10);
     if (const char* e = getenv("PT_WF_TAIL_CUT")) c->tailCut = (uint32_t)strtoul(e, nullptr, 10);
     hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (se != hipSuccess) { delete c; return fail(PT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(se)); }

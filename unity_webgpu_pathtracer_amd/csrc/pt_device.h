@@ -1352,12 +1352,10 @@ PT_DEV void path_init(const PTFrameParams& P, uint32_t seedRoot, uint32_t curren
 // to), BEFORE the BSDF is sampled.  The wavefront shade kernel writes them to the slot arrays there, so that their 15
 // registers are free while sample_brdf runs (pt_wavefront.hip); the other schedules keep them in registers and pass nothing.
 struct NoNeeSink { PT_DEV void operator()(PathRegs&) const {} };
-template <bool STATS, bool INLINE_RESOLVE = true, class NeeSink = NoNeeSink>
-PT_DEV void path_step(const DScene& S, const PTFrameParams& P, PathRegs& r, const HitRecord& rec, bool occEnv, bool occLight,
-                      uint32_t pixelX, uint32_t pixelY, uint32_t pixelIndex,
-                      const float4* __restrict__ accumulated, float4* __restrict__ output, Counters& cn, NeeSink neeSink = NeeSink())
+
+// ---- (1) radiance += DirectLight(...) * throughput      (util/pathtrace.hlsl:93, deferred until the shadow rays are in)
+PT_DEV void path_apply_pending(PathRegs& r, bool occEnv, bool occLight)
 {
-    // ---- (1) radiance += DirectLight(...) * throughput      (util/pathtrace.hlsl:93, deferred until the shadow rays are in)
     if (r.hasPending) {
         v3 Ld = mk3(0.0f);
         if (r.env.valid == 1u && !occEnv) Ld = Ld + r.env.contribution;
@@ -1367,9 +1365,15 @@ PT_DEV void path_step(const DScene& S, const PTFrameParams& P, PathRegs& r, cons
         r.hasPending = false;
         r.green = false;
     }
+}
 
-    // ---- (2) shade the closest hit                           (util/pathtrace.hlsl:27-127)
-    if (r.state == PS_TRACE) {
+// ---- (2) shade the closest hit                           (util/pathtrace.hlsl:27-127).  Precondition: r.state == PS_TRACE.
+// Reads r.ro, rd, radiance, throughput, scatterPdf, maxRoughness, rng, depth; writes those plus state, hasPending, green,
+// env, light, neeOrigin, pendThroughput.
+template <bool STATS, class NeeSink = NoNeeSink>
+PT_DEV void path_shade_hit(const DScene& S, const PTFrameParams& P, PathRegs& r, const HitRecord& rec, Counters& cn, NeeSink neeSink = NeeSink())
+{
+    {
         const uint32_t maxRayBounces = P.MaxRayBounces > 1u ? P.MaxRayBounces : 1u;
         SurfHit hit;
         hit.distance = PT_FAR_PLANE;
@@ -1451,8 +1455,13 @@ PT_DEV void path_step(const DScene& S, const PTFrameParams& P, PathRegs& r, cons
             }
         }
     }
+}
 
-    // ---- (3) end of a sample                                 (PathTracer.compute:77-98)
+// ---- (3) end of a sample                                 (PathTracer.compute:77-98)
+template <bool INLINE_RESOLVE>
+PT_DEV void path_end_sample(const PTFrameParams& P, PathRegs& r, uint32_t pixelX, uint32_t pixelY, uint32_t pixelIndex,
+                            const float4* __restrict__ accumulated, float4* __restrict__ output, Counters& cn)
+{
     if (r.state == PS_ENDING && !r.hasPending) {
         if (P.UseFireflyFilter) {
             float lum = luminance3(r.radiance);
@@ -1483,6 +1492,16 @@ PT_DEV void path_step(const DScene& S, const PTFrameParams& P, PathRegs& r, cons
             r.state = PS_DONE;
         }
     }
+}
+
+template <bool STATS, bool INLINE_RESOLVE = true, class NeeSink = NoNeeSink>
+PT_DEV void path_step(const DScene& S, const PTFrameParams& P, PathRegs& r, const HitRecord& rec, bool occEnv, bool occLight,
+                      uint32_t pixelX, uint32_t pixelY, uint32_t pixelIndex,
+                      const float4* __restrict__ accumulated, float4* __restrict__ output, Counters& cn, NeeSink neeSink = NeeSink())
+{
+    path_apply_pending(r, occEnv, occLight);
+    if (r.state == PS_TRACE) path_shade_hit<STATS, NeeSink>(S, P, r, rec, cn, neeSink);
+    path_end_sample<INLINE_RESOLVE>(P, r, pixelX, pixelY, pixelIndex, accumulated, output, cn);
 }
 
 // Wave-level helpers (wave64).

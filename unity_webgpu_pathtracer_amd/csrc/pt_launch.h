@@ -91,6 +91,7 @@ struct PTWfBuffers {
     uint4* susp;                // [numSlots / 64][PT_WF_SUSPEND][6]: suspended rays of the refill trace kernel (pt_wavefront.hip)
     uint32_t* suspCount;        // [numSlots / 64]
     uint32_t* aliveFlags;       // [maxIterations][PT_WF_ALIVE_SHARDS] slots still alive after shade launch i of the pass (tail cut, pt_wavefront.hip)
+    uint32_t shadeSorted;       // wavefront shade launches: 1 = pt_wf_shade_sorted (stage 2 regrouped through LDS), 0 = pt_wf_shade (slot order)
     uint32_t tailCut;           // later launches of a pass return at once when fewer slots than this are alive; pt_wf_cleanup finishes them
     uint32_t* chunkHeads;       // [8 shards x 32 words]: work counters of the persistent trace kernel, one 128-B line each
     unsigned long long* statRows;   // [numStatRows][16]
@@ -142,6 +143,11 @@ hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const PT
 #ifndef PT_WF_SUSPEND
 #define PT_WF_SUSPEND 16u       // refill trace kernel: a wave whose range is exhausted stops when this many rays or fewer are left, and leaves them
                                 // as records for the tail launch (pt_wavefront.hip); 0 = off.  Also the record slots per trace wave (pt_api.hip)
+#endif
+#ifndef PT_WF_SHADE_SORTED
+#define PT_WF_SHADE_SORTED 0u     // shade kernel of the wavefront schedules (PTWfBuffers.shadeSorted): 0 = pt_wf_shade (slot order), 1 = pt_wf_shade_sorted.
+                                  // Measured (Sponza-class 1080p / 8 spp): sorted issues 25 % fewer VALU instructions at 54 % instead of 38 % lane utilisation
+                                  // and is 13 % SLOWER end to end -- see the kernel's header
 #endif
 #define PT_WF_ALIVE_SHARDS 64u   // words per iteration of PTWfBuffers.aliveFlags (power of two <= 64)
 #ifndef PT_WF_TAIL_CUT

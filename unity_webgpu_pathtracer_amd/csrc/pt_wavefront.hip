@@ -1299,6 +1299,205 @@ __global__ __launch_bounds__(64, PT_WF_FUSED_WAVES) void pt_wf_fused(DScene S, P
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// shade, regrouped through LDS (round 3).  path_step() is three stages: (1) add the pending NEE of the last bounce, (2) shade the
+// closest hit that came back -- attributes, lights, material + textures, two NEE evaluations, BSDF sampling, roulette: ~90 % of the
+// kernel's instructions -- and (3) end-of-sample bookkeeping / next camera ray.  In slot order a wave runs stage 2 with whatever
+// lanes happen to need it: 75 % of the slots are alive, about 60 % of those have a surface hit, and the wave still issues every
+// instruction of every branch any lane takes (38 % VALU lane utilisation, profiles/r03_pmc.json).  Sorting the slot LIST fixed
+// that and lost to the state gathers it caused (round 2: shade VALU -41 %, throughput -20 %).
+//
+// Here loads and stores stay coalesced in slot order (the HOME lane of a slot runs stages 1 and 3 and does all global state
+// traffic), and only stage 2 is regrouped: inside a 256-slot workgroup the slots that need it are ranked -- surface hits first,
+// then misses / light candidates, stable in slot order -- their stage-2 inputs (20 words) go to LDS record [rank], lane i of the
+// workgroup shades record i, writes the 31 words of results back in place, and the home lanes pick them up.  Waves of the workgroup
+// are therefore full surface-hit waves, at most one mixed wave, and waves with nothing to shade, which skip stage 2 altogether.
+// The values a path sees are those of path_step() in the same order: frames and counters are bit-identical.
+// LDS: 35 fields x 256 x 4 B = 35 KB per workgroup, SoA (one ds_*_b32 per field and lane, conflict-free) -> 4 workgroups per CU.
+//
+// MEASURED (round 3, Sponza-class 1080p / 8 spp; tools/experiments/sorted_pmc.sh): SQ_INSTS_VALU of the shade launches 4.46e9 ->
+// 3.35e9 per pass (-25 %), lanes per VALU instruction 38 % -> 54 %, bit-identical frames and counters (the parity suite runs it) --
+// and the launches take 9.8 instead of 7.7 ms per pass, the pipelined bench 4,390 instead of 5,030 Mrays/s.  The shade step is a
+// chain of dependent fetches (state -> attributes -> material -> texels -> lights) that needs many waves in flight to hide; after
+// the regrouping a workgroup's surface hits sit in ~2 of its 4 waves and the other two WAIT at the barriers holding their
+// registers and the workgroup's LDS: per CU, 6-7 waves do stage 2 where 16 one-wave workgroups did before.  Fewer instructions,
+// fewer waves to overlap their latency -- the second effect wins.  Kept as a variant (PT_WF_SHADE_SORTED=1 in the environment
+// selects it); what would cash the instruction saving in is a regrouping that does not park waves: stage 2 as its own launch
+// over compacted records.
+// ------------------------------------------------------------------------------------------
+#define PT_SH_FIELDS 31u
+#define PT_SH_HOME 4u
+template <bool STATS>
+__global__ __launch_bounds__(256, PT_WF_SHADE_MIN_WAVES) void pt_wf_shade_sorted(DScene S, PTFrameParams P, PTTileMap tm, PTWfBuffers B, uint32_t iteration)
+{
+    __shared__ uint32_t s_rec[PT_SH_FIELDS][256];      // stage-2 records, field-major
+    __shared__ uint32_t s_home[PT_SH_HOME][256];       // what a home lane parks across stage 2: throughput before the bounce (or radiance / rng of a slot that skips stage 2)
+    __shared__ uint32_t s_cnt[2][4];                   // per wave: slots of class 0 (surface hit), class 1 (miss)
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint32_t slot = blockIdx.x * 256u + tid;
+    if (blockIdx.x == 0u && tid < PT_WF_SHARDS) B.chunkHeads[tid * 32u] = 0u;   // for the next trace launch (schedule 3)
+    if (tail_cut(B, iteration)) return;
+    Counters cn = {};
+    const uint32_t f = B.flags[slot];
+    const bool live = fl_state(f) != PS_DONE;
+    auto put = [&](uint32_t field, uint32_t idx, uint32_t v) { s_rec[field][idx] = v; };
+    auto putf = [&](uint32_t field, uint32_t idx, float v) { s_rec[field][idx] = pt_asuint(v); };
+    auto get = [&](uint32_t field, uint32_t idx) -> uint32_t { return s_rec[field][idx]; };
+    auto getf = [&](uint32_t field, uint32_t idx) -> float { return pt_asfloat(s_rec[field][idx]); };
+
+    // ---- stage 1 at home: the slot's state (one batch of coalesced loads), pending NEE applied
+    uint32_t key = 2u;                                              // 0: surface hit to shade, 1: miss (sky / analytic light), 2: no stage 2
+    {
+        uint32_t rng = B.rng[slot];
+        float4 qro = B.ray[0][2u * slot], qrd = B.ray[0][2u * slot + 1u], qrad = B.rad[slot], qthr = B.thr[slot];
+        float4 qenvC = B.envC[slot], qlightC = B.lightC[slot], qpthr = B.pthr[slot], qhit = B.hit[slot];
+        uint32_t o0 = B.occl[slot], o1 = B.occl[(size_t)B.numSlots + slot];
+        float4 qhit2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (S.hasTlas) qhit2 = B.hit2[slot];
+        asm volatile("" : "+v"(rng), "+v"(qro.x), "+v"(qrd.x), "+v"(qrad.x), "+v"(qthr.x), "+v"(qenvC.x), "+v"(qlightC.x), "+v"(qpthr.x), "+v"(qhit.x), "+v"(o0), "+v"(o1), "+v"(qhit2.x));
+        if (live) {
+            PathRegs r;
+            r.state = fl_state(f);
+            r.hasPending = fl_pending(f);
+            r.env.valid = fl_env(f);
+            r.light.valid = fl_light(f);
+            r.green = (f >> 6) & 1u;
+            r.radiance = xyz(qrad);
+            r.env.contribution = r.hasPending ? xyz(qenvC) : mk3(0.0f);
+            r.light.contribution = r.hasPending ? xyz(qlightC) : mk3(0.0f);
+            r.pendThroughput = r.hasPending ? xyz(qpthr) : mk3(0.0f);
+            const bool occEnv = r.hasPending && o0 != 0u, occLight = r.hasPending && o1 != 0u;
+            path_apply_pending(r, occEnv, occLight);
+            if (r.state == PS_TRACE) key = qhit.x < PT_FAR_PLANE ? 0u : 1u;
+            qrad = f4(r.radiance, 0.0f);
+        }
+        // ---- rank the slots that need stage 2 (stable partition of the workgroup's 256 slots: class 0, then class 1)
+        const unsigned long long m0 = __ballot(key == 0u), m1 = __ballot(key == 1u);
+        if (lane == 0u) { s_cnt[0][wave] = (uint32_t)__popcll(m0); s_cnt[1][wave] = (uint32_t)__popcll(m1); }
+        __syncthreads();
+        uint32_t base0 = 0u, base1 = 0u, total0 = 0u, total1 = 0u;
+#pragma unroll
+        for (uint32_t w = 0; w < 4u; ++w) {
+            const uint32_t c0 = s_cnt[0][w], c1 = s_cnt[1][w];
+            if (w < wave) { base0 += c0; base1 += c1; }
+            total0 += c0; total1 += c1;
+        }
+        const uint32_t dest = key == 0u ? base0 + rank_below(m0) : (key == 1u ? total0 + base1 + rank_below(m1) : 0xFFFFu);
+        key |= dest << 2;                                            // the lane's own ticket, kept across stage 2 in ONE register
+        key |= (total0 + total1) << 20;
+        if (dest != 0xFFFFu) {
+            putf(0, dest, qro.x); putf(1, dest, qro.y); putf(2, dest, qro.z);
+            putf(3, dest, qrd.x); putf(4, dest, qrd.y); putf(5, dest, qrd.z);
+            put(6, dest, rng); put(7, dest, f >> 19);               // depth
+            putf(8, dest, qro.w); putf(9, dest, qrd.w);             // scatterPdf, maxRoughness
+            putf(10, dest, qthr.x); putf(11, dest, qthr.y); putf(12, dest, qthr.z);
+            putf(13, dest, qrad.x); putf(14, dest, qrad.y); putf(15, dest, qrad.z);
+            putf(16, dest, qhit.x); putf(17, dest, qhit.y); putf(18, dest, qhit.z); putf(19, dest, qhit.w);
+            if (S.hasTlas) { putf(20, dest, qhit2.x); putf(21, dest, qhit2.y); putf(22, dest, qhit2.z); putf(23, dest, qhit2.w); }
+            s_home[0][tid] = pt_asuint(qthr.x); s_home[1][tid] = pt_asuint(qthr.y); s_home[2][tid] = pt_asuint(qthr.z);    // the throughput the NEE of this bounce applies to
+        } else {
+            s_home[0][tid] = pt_asuint(qrad.x); s_home[1][tid] = pt_asuint(qrad.y); s_home[2][tid] = pt_asuint(qrad.z);
+            s_home[3][tid] = rng;
+        }
+    }
+    __syncthreads();
+
+    // ---- stage 2: lane i shades record i (waves beyond the last record skip it)
+    const uint32_t nWork = key >> 20;
+    if (tid < nWork) {
+        PathRegs w;
+        w.ro = mk3(getf(0, tid), getf(1, tid), getf(2, tid));
+        w.rd = mk3(getf(3, tid), getf(4, tid), getf(5, tid));
+        w.rng = get(6, tid); w.depth = get(7, tid);
+        w.scatterPdf = getf(8, tid); w.maxRoughness = getf(9, tid);
+        w.throughput = mk3(getf(10, tid), getf(11, tid), getf(12, tid));
+        w.radiance = mk3(getf(13, tid), getf(14, tid), getf(15, tid));
+        HitRecord ch;
+        ch.h.t = getf(16, tid); ch.h.u = getf(17, tid); ch.h.v = getf(18, tid); ch.h.triIndex = get(19, tid);
+        ch.pos = mk3(0.0f); ch.inst = 0u;
+        if (S.hasTlas) { ch.pos = mk3(getf(20, tid), getf(21, tid), getf(22, tid)); ch.inst = get(23, tid); }
+        w.state = PS_TRACE; w.hasPending = false; w.green = false; w.sampleIdx = 0u;
+        w.color = mk3(0.0f);
+        w.env.valid = 0u; w.light.valid = 0u;
+        w.env.dir = mk3(0.0f); w.light.dir = mk3(0.0f); w.neeOrigin = mk3(0.0f);
+        w.env.contribution = mk3(0.0f); w.light.contribution = mk3(0.0f); w.pendThroughput = mk3(0.0f);
+        // the NEE rays of the bounce go to the record as soon as they are final: their 15 registers are free while the BSDF is sampled
+        struct Sink {
+            uint32_t (*rec)[256]; uint32_t i;
+            PT_DEV void operator()(PathRegs& q) const {
+                rec[16][i] = pt_asuint(q.neeOrigin.x); rec[17][i] = pt_asuint(q.neeOrigin.y); rec[18][i] = pt_asuint(q.neeOrigin.z);
+                rec[19][i] = pt_asuint(q.env.dir.x); rec[20][i] = pt_asuint(q.env.dir.y); rec[21][i] = pt_asuint(q.env.dir.z);
+                rec[22][i] = pt_asuint(q.light.dir.x); rec[23][i] = pt_asuint(q.light.dir.y); rec[24][i] = pt_asuint(q.light.dir.z);
+                rec[25][i] = pt_asuint(q.env.contribution.x); rec[26][i] = pt_asuint(q.env.contribution.y); rec[27][i] = pt_asuint(q.env.contribution.z);
+                rec[28][i] = pt_asuint(q.light.contribution.x); rec[29][i] = pt_asuint(q.light.contribution.y); rec[30][i] = pt_asuint(q.light.contribution.z);
+            }
+        };
+        path_shade_hit<STATS, Sink>(S, P, w, ch, cn, Sink{s_rec, tid});
+        putf(0, tid, w.ro.x); putf(1, tid, w.ro.y); putf(2, tid, w.ro.z);
+        putf(3, tid, w.rd.x); putf(4, tid, w.rd.y); putf(5, tid, w.rd.z);
+        put(6, tid, w.rng);
+        put(7, tid, (w.state & 3u) | ((w.hasPending ? 1u : 0u) << 2) | ((w.env.valid & 3u) << 3) | ((w.light.valid & 1u) << 5) | ((w.green ? 1u : 0u) << 6) | ((w.depth & 0x1FFFu) << 19));
+        putf(8, tid, w.scatterPdf); putf(9, tid, w.maxRoughness);
+        putf(10, tid, w.throughput.x); putf(11, tid, w.throughput.y); putf(12, tid, w.throughput.z);
+        putf(13, tid, w.radiance.x); putf(14, tid, w.radiance.y); putf(15, tid, w.radiance.z);
+    }
+    __syncthreads();
+
+    // ---- stage 3 at home: results of stage 2 (if any), end of the sample, coalesced stores
+    bool alive = false;
+    if (live) {
+        uint32_t px, py, pass;
+        pt_slot_to_pixel(tm, pixel_slot_of(B, slot, pass), px, py);
+        const uint32_t dest = (key >> 2) & 0xFFFFu;
+        PathRegs r;
+        r.sampleIdx = (f >> 7) & 0xFFFu;
+        r.color = xyz(B.color[slot]);
+        r.env.dir = mk3(0.0f); r.light.dir = mk3(0.0f); r.neeOrigin = mk3(0.0f);
+        r.env.contribution = mk3(0.0f); r.light.contribution = mk3(0.0f); r.pendThroughput = mk3(0.0f);
+        r.env.valid = 0u; r.light.valid = 0u;
+        bool writeNee = false;
+        if (dest != 0xFFFFu) {
+            const uint32_t m = get(7, dest);
+            r.state = m & 3u; r.hasPending = (m >> 2) & 1u; r.env.valid = (m >> 3) & 3u; r.light.valid = (m >> 5) & 1u; r.green = (m >> 6) & 1u;
+            r.depth = m >> 19;
+            r.ro = mk3(getf(0, dest), getf(1, dest), getf(2, dest));
+            r.rd = mk3(getf(3, dest), getf(4, dest), getf(5, dest));
+            r.rng = get(6, dest);
+            r.scatterPdf = getf(8, dest); r.maxRoughness = getf(9, dest);
+            r.throughput = mk3(getf(10, dest), getf(11, dest), getf(12, dest));
+            r.radiance = mk3(getf(13, dest), getf(14, dest), getf(15, dest));
+            if (r.hasPending) {
+                writeNee = true;
+                r.neeOrigin = mk3(getf(16, dest), getf(17, dest), getf(18, dest));
+                r.env.dir = mk3(getf(19, dest), getf(20, dest), getf(21, dest));
+                r.light.dir = mk3(getf(22, dest), getf(23, dest), getf(24, dest));
+                r.env.contribution = mk3(getf(25, dest), getf(26, dest), getf(27, dest));
+                r.light.contribution = mk3(getf(28, dest), getf(29, dest), getf(30, dest));
+                r.pendThroughput = mk3(pt_asfloat(s_home[0][tid]), pt_asfloat(s_home[1][tid]), pt_asfloat(s_home[2][tid]));
+            }
+        } else {
+            // no closest hit to shade: the path was waiting for its last NEE (state ENDING)
+            r.state = fl_state(f); r.hasPending = false; r.green = false;
+            r.depth = f >> 19;
+            r.radiance = mk3(pt_asfloat(s_home[0][tid]), pt_asfloat(s_home[1][tid]), pt_asfloat(s_home[2][tid]));
+            r.rng = s_home[3][tid];
+            const float4 qro = B.ray[0][2u * slot], qrd = B.ray[0][2u * slot + 1u], qthr = B.thr[slot];
+            r.ro = xyz(qro); r.scatterPdf = qro.w;
+            r.rd = xyz(qrd); r.maxRoughness = qrd.w;
+            r.throughput = xyz(qthr);
+        }
+        path_end_sample<false>(P, r, px, py, py * P.OutputWidth + px, nullptr, nullptr, cn);
+        store_path(B, slot, r, writeNee);
+        alive = r.state != PS_DONE;
+    }
+    {
+        const uint32_t nAlive = (uint32_t)__popcll(__ballot(alive));
+        if (B.tailCut != 0u && nAlive && lane == 0u)
+            atomicAdd(&B.aliveFlags[iteration * PT_WF_ALIVE_SHARDS + (blockIdx.x & (PT_WF_ALIVE_SHARDS - 1u))], nAlive);
+    }
+    flush_counters<STATS>(cn, B.statRows, blockIdx.x * 4u + wave, lane);
+}
+
 // cleanup: pixels still alive after the fixed number of iterations are run to completion here, one lane per slot with
 // the megakernel's loop (trace <= 3 rays, path_step, repeat).  Normally a handful of lanes; correctness for any path length.
 template <bool STATS, bool TLAS>
@@ -1501,8 +1700,13 @@ hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const PT
             if (fullStats) hipLaunchKernelGGL((pt_wf_trace<true, false>), dim3(nb * 3u), dim3(256), 0, stream, S, B, it);
             else hipLaunchKernelGGL((pt_wf_trace<false, false>), dim3(nb * 3u), dim3(256), 0, stream, S, B, it);
         }
-        if (fullStats) hipLaunchKernelGGL(pt_wf_shade<true>, dim3(B.numSlots / PT_WF_SHADE_BLOCK), dim3(PT_WF_SHADE_BLOCK), 0, stream, S, P, tm, B, it);
-        else hipLaunchKernelGGL(pt_wf_shade<false>, dim3(B.numSlots / PT_WF_SHADE_BLOCK), dim3(PT_WF_SHADE_BLOCK), 0, stream, S, P, tm, B, it);
+        if (B.shadeSorted) {
+            if (fullStats) hipLaunchKernelGGL(pt_wf_shade_sorted<true>, dim3(nb), dim3(256), 0, stream, S, P, tm, B, it);
+            else hipLaunchKernelGGL(pt_wf_shade_sorted<false>, dim3(nb), dim3(256), 0, stream, S, P, tm, B, it);
+        } else {
+            if (fullStats) hipLaunchKernelGGL(pt_wf_shade<true>, dim3(B.numSlots / PT_WF_SHADE_BLOCK), dim3(PT_WF_SHADE_BLOCK), 0, stream, S, P, tm, B, it);
+            else hipLaunchKernelGGL(pt_wf_shade<false>, dim3(B.numSlots / PT_WF_SHADE_BLOCK), dim3(PT_WF_SHADE_BLOCK), 0, stream, S, P, tm, B, it);
+        }
         launches += 2;
     }
     const uint32_t cleanupBlocks = nb < 1024u ? nb : 1024u;          // 256 CUs x 4 workgroups; each strides over the slot blocks
