@@ -160,6 +160,8 @@ def main():
     ap.add_argument("--no-alg-replay", action="store_true", help="profiling runs: skip the untimed full-counter replay (roofline.achieved is then null)")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads reported under 'other_workloads'")
     ap.add_argument("--passes-in-flight", type=int, default=0, help="PTSetPassesInFlight: 0 = library default for GPU_MAX_HW_QUEUES, 1 = passes back to back")
+    ap.add_argument("--latency-sub-frames", type=int, default=0, help="PTSetSubFrames for the latency leg (0 = the library's passes in flight, at most 6)")
+    ap.add_argument("--sub-frames", type=int, default=1, help="PTSetSubFrames for the timed (pipelined) run")
     ap.add_argument("--latency-steps", type=int, default=6, help="passes of the latency leg (host synchronises after every pass); 0 = skip")
     ap.add_argument("--build-device", action="store_true", help="also render over the tree PTBuildBVHDevice builds on the GPU (reported under 'device_built_tree')")
     ap.add_argument("--batch", type=int, default=0, help="passes per launch sequence (PTRenderPassBatchTo, 1..8): the steps are issued in groups of this many -- same frames, "
@@ -219,6 +221,8 @@ def main():
         pt.set_schedule(args.schedule)
         if args.passes_in_flight:
             pt.set_passes_in_flight(args.passes_in_flight)
+        if args.sub_frames > 1:
+            pt.set_sub_frames(args.sub_frames)
         if args.wf_iterations:
             pt.set_wavefront_iterations(args.wf_iterations)
         frames = [torch.zeros((H, W, 4), dtype=torch.float32, device=device) for _ in range(2)]
@@ -317,6 +321,8 @@ def main():
             pt.set_stats_level(0)
             pt.synchronize()
             pt.reset_stats()
+            sub = args.latency_sub_frames or min(4, pt.passes_in_flight())
+            pt.set_sub_frames(max(1, sub))
             c2, t_lat = cur, []
             for k in range(warmup + steps, warmup + steps + args.latency_steps):
                 p = scenes.frame_params(scene, W, H, spp=SPP, current_sample=k * SPP, seed=seed_of(k), max_bounces=args.bounces)
@@ -326,9 +332,10 @@ def main():
                 t_lat.append(time.perf_counter() - t1)
                 c2 = 1 - c2
             ls = pt.stats()
+            pt.set_sub_frames(max(1, args.sub_frames))
             lat = sorted(t_lat)[len(t_lat) // 2]
             res["latency_mode"] = {"ms_per_pass": round(lat * 1e3, 4), "mrays_per_s": round(ls.rays / len(t_lat) / lat / 1e6, 3),
-                                   "passes": len(t_lat), "ms_per_pass_all": [round(t * 1e3, 3) for t in t_lat],
+                                   "passes": len(t_lat), "sub_frames": max(1, sub), "ms_per_pass_all": [round(t * 1e3, 3) for t in t_lat],
                                    "what": "median wall time of one pass when the host synchronises after every pass (enqueue + "
                                            "device + hipStreamSynchronize): one pass in flight, as under the reference's "
                                            "OnRenderImage -> Blit (PathTracer.cs:251-272); `value` keeps several passes in flight"}

@@ -348,6 +348,11 @@ PT_API int PTSetWavefrontIterations(PTContext* ctx, int iterations);
  * every value. */
 PT_API int PTSetPassesInFlight(PTContext* ctx, int passes);
 PT_API int PTGetPassesInFlight(PTContext* ctx);
+/* Wavefront schedules: cut every pass into `subFrames` (1 .. passes in flight) interleaved subsets of the context's 16x16 pixel
+ * blocks, each rendered by its own launch sequence on its own state set and stream into the same output frame.  For a host that
+ * consumes every frame before it asks for the next (the reference presents every pass, PathTracer.cs:251-272) this gives ONE
+ * pass the overlap that otherwise only several passes in flight have.  Same frame for every value; 1 (default) = off. */
+PT_API int PTSetSubFrames(PTContext* ctx, int subFrames);
 
 /* Text of the last error on the calling thread ("" if none). */
 PT_API const char* PTGetLastError(void);

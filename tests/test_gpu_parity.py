@@ -255,6 +255,29 @@ def test_pass_batch_equals_sequential_passes(schedule):
         pt.close()
 
 
+@pytest.mark.parametrize("schedule,world", [(1, 1), (4, 1), (1, 3)])
+def test_sub_frames_do_not_change_a_bit(oracle, schedule, world):
+    """PTSetSubFrames: every pass cut into three interleaved sub-frames with their own launch sequences, state sets and streams,
+    all writing one output frame -- two progressive passes equal the oracle's bit for bit; with tile ownership the pixels of other
+    ranks stay exact zeros."""
+    s = scenes.material_zoo()
+    W, H, SPP = 200, 120, 2
+    rank = world - 1
+    pt = PathTracer(s, width=W, height=H, samplesPerPass=SPP, schedule=schedule, rank=rank, world_size=world)
+    pt.set_sub_frames(3)
+    seeds = [0xABCDEF01, 0x10FEDCBA]
+    params, ref = [], None
+    for seed in seeds:
+        params.append(pt.params(seed))
+        pt.OnRenderImage(seed)
+    gpu = pt.readback()
+    for p in params:
+        ref, st = _oracle_frame(oracle, pt, p, accumulated=ref, tile_rank=rank, tile_world=world)
+    _, nbad = _compare(gpu, ref, f"sub-frames, schedule {schedule}, world {world}")
+    assert nbad == 0
+    pt.close()
+
+
 def test_render_pass_to_caller_buffers(oracle):
     """PTRenderPassTo with caller-owned device frames (torch tensors), ping-ponged by the caller as bench.py does."""
     import torch

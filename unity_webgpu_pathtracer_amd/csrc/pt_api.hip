@@ -111,6 +111,7 @@ struct PTContext {
         hipEvent_t callEv = nullptr, done = nullptr;
     } sets[PT_WF_SETS];
     uint32_t nextSet = 0;
+    uint32_t subFrames = 1;                     // launch chains a pass is cut into (PTSetSubFrames)
     uint32_t numSets = 0;                       // passes in flight = state sets in use (PTSetPassesInFlight); carved on first use
     uint32_t wfIterations = 0;                  // 0 = automatic
     uint32_t shadeSorted = PT_WF_SHADE_SORTED;  // PT_WF_SHADE_SORTED in the environment overrides (experiments)
@@ -416,27 +417,41 @@ int render_to(PTContext* c, const PTFrameParams* hostParams, float4* dOut, const
         const uint32_t bounces = p->MaxRayBounces > 1u ? p->MaxRayBounces : 1u;
         if (spp > 4095u || bounces > 8191u) return fail(PT_ERR_UNSUPPORTED, "wavefront schedules pack SamplesPerPass <= 4095 and MaxRayBounces <= 8191");
         const uint64_t maxIt = (uint64_t)spp * (bounces + 2u) + 4u;
-        if (c->nextSet >= c->numSets) c->nextSet = 0u;
-        PTContext::WfSet& set = c->sets[c->nextSet];
-        c->nextSet = (c->nextSet + 1u) % c->numSets;
-        // every set IN USE is carved on the FIRST pass of a frame size (a no-op afterwards): a caller that times passes after a
-        // short warm-up must not find the allocation of sets it has not reached yet inside its timed region.  Sets beyond
-        // PTSetPassesInFlight are never allocated (0.6 GB each at 1080p).
-        const uint32_t slotsPerPass = pt_num_slots(tm);
-        if ((uint64_t)slotsPerPass * batch.count > 0x3FFFFFFFull) return fail(PT_ERR_UNSUPPORTED, "batch too large: passes x owned pixels exceeds 2^30 slots");
-        for (uint32_t k = 0; k < c->numSets; ++k) {
-            if ((rc = ensure_wavefront(c, c->sets[k], slotsPerPass * batch.count, (uint32_t)(maxIt > 65536u ? 65536u : maxIt)))) return rc;
-            c->sets[k].wf.slotsPerPass = slotsPerPass;
+        // A pass may be cut into SUB-FRAMES (PTSetSubFrames): interleaved subsets of the context's 16x16 blocks, each with its own
+        // launch sequence on its own state set and stream, all writing the same output frame.  To the kernels a sub-frame is
+        // tile ownership (rank + world * j of world * S); to the machine it is what a second pass in flight is -- other kernels to
+        // fill the ramp-up and drain of every launch -- without the host having to run ahead of the frame it shows.
+        uint32_t S = c->subFrames < 1u ? 1u : c->subFrames;
+        if (S > c->numSets) S = c->numSets;
+        const bool zeroOnce = c->world > 1 && S > 1u;
+        if (zeroOnce) HIP_TRY(hipMemsetAsync(dOut, 0, (size_t)p->OutputWidth * p->OutputHeight * sizeof(float4), c->stream));
+        for (uint32_t j = 0; j < S; ++j) {
+            const PTTileMap tmj = S == 1u ? tm : pt_make_tile_map(*p, c->rank + c->world * (int)j, c->world * (int)S);
+            if (c->nextSet >= c->numSets) c->nextSet = 0u;
+            PTContext::WfSet& set = c->sets[c->nextSet];
+            c->nextSet = (c->nextSet + 1u) % c->numSets;
+            // every set IN USE is carved on the FIRST pass of a frame size (a no-op afterwards): a caller that times passes after a
+            // short warm-up must not find the allocation of sets it has not reached yet inside its timed region.  Sets beyond
+            // PTSetPassesInFlight are never allocated (0.6 GB each at 1080p).
+            const uint32_t slotsPerPass = pt_num_slots(tmj);
+            if ((uint64_t)slotsPerPass * batch.count > 0x3FFFFFFFull) return fail(PT_ERR_UNSUPPORTED, "batch too large: passes x owned pixels exceeds 2^30 slots");
+            if (j == 0u)
+                for (uint32_t k = 0; k < c->numSets; ++k) {
+                    if ((rc = ensure_wavefront(c, c->sets[k], slotsPerPass * batch.count, (uint32_t)(maxIt > 65536u ? 65536u : maxIt)))) return rc;
+                    c->sets[k].wf.slotsPerPass = slotsPerPass;
+                }
+            // the launch chain runs on the set's own stream; only its resolve (which reads `accumulated` and writes `output`)
+            // is ordered after what the caller has enqueued on the context stream so far, the previous pass included
+            HIP_TRY(hipEventRecord(set.callEv, c->stream));
+            if (c->profiling && j == 0u) HIP_TRY(hipEventRecord(ep.start, set.stream));
+            uint32_t n = 0;
+            HIP_TRY(pt_launch_wavefront(c->scene, *p, batch, dAcc, dOut, tmj, set.wf, c->dStats, c->statsLevel > 0, set.stream, set.callEv,
+                                        c->world > 1 && !zeroOnce, &n, schedule == 4 ? 4 : (schedule == 1 ? 2 : (schedule == 2 ? 1 : 0)), c->wfIterations));
+            launches += n;
+            if (c->profiling && j + 1u == S) HIP_TRY(hipEventRecord(ep.stop, set.stream));
+            HIP_TRY(hipEventRecord(set.done, set.stream));
+            HIP_TRY(hipStreamWaitEvent(c->stream, set.done, 0));          // consumers of the context stream see the finished frame
         }
-        // the launch chain runs on the set's own stream; only its resolve (which reads `accumulated` and writes `output`)
-        // is ordered after what the caller has enqueued on the context stream so far, the previous pass included
-        HIP_TRY(hipEventRecord(set.callEv, c->stream));
-        if (c->profiling) HIP_TRY(hipEventRecord(ep.start, set.stream));
-        HIP_TRY(pt_launch_wavefront(c->scene, *p, batch, dAcc, dOut, tm, set.wf, c->dStats, c->statsLevel > 0, set.stream, set.callEv,
-                                    c->world > 1, &launches, schedule == 4 ? 4 : (schedule == 1 ? 2 : (schedule == 2 ? 1 : 0)), c->wfIterations));
-        if (c->profiling) HIP_TRY(hipEventRecord(ep.stop, set.stream));
-        HIP_TRY(hipEventRecord(set.done, set.stream));
-        HIP_TRY(hipStreamWaitEvent(c->stream, set.done, 0));          // consumers of the context stream see the finished frame
         break;
     }
     case 0:
@@ -924,6 +939,13 @@ PT_API int PTSetPassesInFlight(PTContext* c, int passes)
         PTContext::WfSet& set = c->sets[k];
         if (set.arena) { hipFree(set.arena); set.arena = nullptr; set.arenaBytes = 0; set.wf = PTWfBuffers{}; }
     }
+    return PT_OK;
+}
+
+PT_API int PTSetSubFrames(PTContext* c, int subFrames)
+{
+    if (!c || subFrames < 1 || subFrames > PT_WF_SETS) return fail(PT_ERR_INVALID_ARG, "ctx == NULL or subFrames outside 1.." + std::to_string(PT_WF_SETS));
+    c->subFrames = (uint32_t)subFrames;
     return PT_OK;
 }
 

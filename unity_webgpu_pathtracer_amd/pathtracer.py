@@ -267,6 +267,10 @@ class PathTracer:
         """0 = default for the hardware queues the process asked for (GPU_MAX_HW_QUEUES); 1 = passes back to back."""
         plugin.check(self.lib.PTSetPassesInFlight(self.ctx, n))
 
+    def set_sub_frames(self, n: int):
+        """PTSetSubFrames: cut every pass into n interleaved sub-frames with their own launch sequences (1 = off)."""
+        plugin.check(self.lib.PTSetSubFrames(self.ctx, n))
+
     def passes_in_flight(self) -> int:
         return self.lib.PTGetPassesInFlight(self.ctx)
 

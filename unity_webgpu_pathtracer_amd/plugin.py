@@ -70,7 +70,7 @@ def load_library():
         "PTPresent": (i32, [vp, C.POINTER(abi.PTPresentParams), vp, vp]),
         "PTPresentToHost": (i32, [vp, C.POINTER(abi.PTPresentParams), vp, C.c_uint64]),
         "PTSetSchedule": (i32, [vp, i32]), "PTGetSchedule": (i32, [vp]), "PTSetWavefrontIterations": (i32, [vp, i32]),
-        "PTSetPassesInFlight": (i32, [vp, i32]), "PTGetPassesInFlight": (i32, [vp]),
+        "PTSetPassesInFlight": (i32, [vp, i32]), "PTGetPassesInFlight": (i32, [vp]), "PTSetSubFrames": (i32, [vp, i32]),
         "PTGetOwnedTileSlots": (i32, [vp, C.POINTER(abi.PTFrameParams), C.POINTER(C.c_uint64)]),
         "PTPackOwnedTiles": (i32, [vp, C.POINTER(abi.PTFrameParams), vp, vp]),
         "PTUnpackTiles": (i32, [vp, C.POINTER(abi.PTFrameParams), i32, i32, vp, vp]),
@@ -95,7 +95,7 @@ EXPORTED_SYMBOLS = [
     "BuildTLAS", "DestroyTLAS", "IsTLASReady", "GetTLASNodesSize", "GetTLASData",
     "PTCreate", "PTDestroy", "PTSetScene", "PTSetTileOwnership", "PTRenderPass", "PTFlipFrames", "PTResetFrames",
     "PTRenderPassTo", "PTRenderPassBatchTo", "PTSynchronize", "PTReadback", "PTGetFramePointer", "PTGetStream", "PTSetStatsLevel", "PTGetStats",
-    "PTResetStats", "PTSetProfiling", "PTGetTimings", "PTResetTimings", "PTProcessMeshes", "PTCopyTextureData", "PTPresent", "PTPresentToHost", "PTSetSchedule", "PTGetSchedule", "PTSetWavefrontIterations", "PTSetPassesInFlight", "PTGetPassesInFlight",
+    "PTResetStats", "PTSetProfiling", "PTGetTimings", "PTResetTimings", "PTProcessMeshes", "PTCopyTextureData", "PTPresent", "PTPresentToHost", "PTSetSchedule", "PTGetSchedule", "PTSetWavefrontIterations", "PTSetPassesInFlight", "PTGetPassesInFlight", "PTSetSubFrames",
     "PTGetOwnedTileSlots", "PTPackOwnedTiles", "PTUnpackTiles", "PTCreateMulti", "PTGroupDestroy", "PTGroupSize", "PTGroupGetContext",
     "PTGroupSetScene", "PTGroupRenderPass", "PTGroupFlipFrames", "PTGroupResetFrames", "PTGroupSynchronize", "PTGroupReadback",
     "PTGroupGetAssembledFrame", "PTGroupGetStats", "PTGroupResetStats",
