@@ -68,6 +68,9 @@ int main(int argc, char** argv)
     const char* dumpPath = argc > 6 ? argv[6] : NULL;
     FILE* dump = dumpPath ? fopen(dumpPath, "wb") : NULL;
     if (dumpPath && !dump) { fprintf(stderr, "cannot write %s\n", dumpPath); return 2; }
+    /* the HOST's choice, before the first HIP call: passes overlap on separate streams, and streams that share one of the runtime's
+     * hardware queues (default 4) serialise; the library sizes its passes in flight to this variable */
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     const char* path = getenv("PT_PLUGIN");
     if (!path) path = "unity_webgpu_pathtracer_amd/lib/libunity-webgpu-pathtracer-plugin.so";
     void* lib = dlopen(path, RTLD_NOW);
