@@ -262,6 +262,13 @@ def main():
                 k += n
             return cur
 
+        if args.batch > 1:
+            # untimed priming, not a step: one FULL batch, so that the state sets are allocated for the largest launch sequence of
+            # the run before the warm-up (whose last group may be shorter); pass 0 of the warm-up overwrites the frame it leaves
+            ps0 = [scenes.frame_params(scene, W, H, spp=SPP, current_sample=0, seed=seed_of(1000 + j), max_bounces=args.bounces) for j in range(args.batch)]
+            for _ in range(max(1, pt.passes_in_flight())):
+                pt.render_batch_to(ps0, frames[0].data_ptr(), 0)
+            sync_all()
         cur = run_steps(0, warmup, 0)
         sync_all()
         pt.reset_stats()

@@ -111,6 +111,7 @@ struct PTContext {
         hipEvent_t callEv = nullptr, done = nullptr;
     } sets[PT_WF_SETS];
     uint32_t nextSet = 0;
+    uint32_t residentWaves = 0;                 // CUs x 4 SIMDs x 8 waves (device property, read once)
     uint32_t subFrames = 1;                     // launch chains a pass is cut into (PTSetSubFrames)
     uint32_t numSets = 0;                       // passes in flight = state sets in use (PTSetPassesInFlight); carved on first use
     uint32_t wfIterations = 0;                  // 0 = automatic
@@ -159,14 +160,16 @@ int ensure_wavefront(PTContext* c, PTContext::WfSet& set, uint32_t numSlots, uin
     set.wf.tailCut = c->tailCut;
     set.wf.shadeSorted = c->shadeSorted;
     if (set.wf.flags && set.wf.numSlots == numSlots && set.wf.maxIterations >= maxIterations && (!needTlas || set.wf.tlasSpill)) return PT_OK;
-    HIP_TRY(hipStreamSynchronize(set.stream));
     const size_t n = numSlots;
     const uint32_t numRows = 4u * (numSlots >> 6);
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
     // trace waves own 64 or 128 consecutive slots (pt_wf_wide_ranges); a wave addresses 64 slab rows and PT_WF_SUSPEND records
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, c->device));
-    const uint32_t residentWaves = (uint32_t)prop.multiProcessorCount * 4u * 8u;
+    if (c->residentWaves == 0u) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+        c->residentWaves = (uint32_t)prop.multiProcessorCount * 4u * 8u;
+    }
+    const uint32_t residentWaves = c->residentWaves;
     // the HAS_TLAS refill kernel always uses PT_WF_RANGE = 128 slots per wave; the plain one 64 or 128 (pt_wf_wide_ranges)
     const size_t traceWaves = pt_wf_max_trace_waves(numSlots, residentWaves);
     const size_t spillBytes = traceWaves * 64u * (size_t)(PT_BVH_STACK_SIZE - PT_WF_LDS_STACK) * sizeof(uint2);
@@ -174,7 +177,13 @@ int ensure_wavefront(PTContext* c, PTContext::WfSet& set, uint32_t numSlots, uin
     const size_t tlasSpillBytes = needTlas ? traceWaves * 64u * (size_t)PT_BVH_STACK_SIZE * sizeof(uint32_t) : 0;
     size_t total = align(n * 4) * 2 + align(n * 16) * PT_F4_COUNT + align(n * 2) + align((size_t)maxIterations * 4 * PT_WF_ALIVE_SHARDS) +
                    align((size_t)numRows * 16 * 8) + align(8 * 32 * 4) + align(spillBytes) + align(suspBytes) + align(traceWaves * 4) + align(tlasSpillBytes);
-    if (set.arena && set.arenaBytes < total) { hipFree(set.arena); set.arena = nullptr; set.arenaBytes = 0; }
+    // The arena only ever grows: a different slot count (another batch size, another frame size) that fits is a new carving of
+    // the same memory -- launches already enqueued on the set's stream keep the pointers they were given and finish first
+    // (stream order), so neither a synchronisation nor an allocation lands in a caller's timed region.
+    if (set.arena && set.arenaBytes < total) {
+        HIP_TRY(hipStreamSynchronize(set.stream));
+        hipFree(set.arena); set.arena = nullptr; set.arenaBytes = 0;
+    }
     if (!set.arena) {
         HIP_TRY(hipMalloc(&set.arena, total));
         set.arenaBytes = total;
