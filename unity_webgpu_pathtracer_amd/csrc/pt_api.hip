@@ -84,7 +84,7 @@ struct RoctxRange {
 struct PTContext {
     int device = 0;
     hipStream_t stream = nullptr;
-    DeviceBuffer nodes, tris, attrs, materials, lights, lightConst, tex, tlas, instances, envTex, envCdf;
+    DeviceBuffer nodes, tris, attrs, materials, lights, lightConst, tex, tlas, instances, instByLeaf, envTex, envCdf;
     void* batchScratch = nullptr;               // PTRenderPassBatchTo under the megakernel: the frame the odd passes of a batch write
     size_t batchScratchBytes = 0;
     void* present = nullptr;                    // PTPresentToHost staging frame
@@ -516,7 +516,7 @@ PT_API int PTDestroy(PTContext* c)
     if (!c) return PT_OK;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
-    for (auto* b : {&c->nodes, &c->tris, &c->attrs, &c->materials, &c->lights, &c->lightConst, &c->tex, &c->tlas, &c->instances, &c->envTex, &c->envCdf}) if (b->ptr) hipFree(b->ptr);
+    for (auto* b : {&c->nodes, &c->tris, &c->attrs, &c->materials, &c->lights, &c->lightConst, &c->tex, &c->tlas, &c->instances, &c->instByLeaf, &c->envTex, &c->envCdf}) if (b->ptr) hipFree(b->ptr);
     for (int i = 0; i < 2; i++) if (c->frames[i]) hipFree(c->frames[i]);
     if (c->dStats) hipFree(c->dStats);
     if (c->present) hipFree(c->present);
@@ -580,6 +580,21 @@ int set_scene(PTContext* c, const PTSceneDesc* hostScene, bool validate)
     if (textures && (rc = upload(c, c->tex, s->textureData, (size_t)s->textureDataUints * 4))) return rc;
     if (tlasOn && (rc = upload(c, c->tlas, s->tlasData, (size_t)s->tlasDataFloats * 4))) return rc;
     if (tlasOn && (rc = upload(c, c->instances, s->gpuInstances, (size_t)s->instanceCount * 144))) return rc;
+    std::vector<float> byLeaf;
+    if (tlasOn) {
+        // what entering an instance reads (util/tlas.hlsl:129-147: TLASData[TLASIndexOffset + k] -> GPUInstance) as ONE record per
+        // index slot k, in the order the TLAS leaves list them: the kernels save a dependent fetch per instance entry
+        const uint64_t indices = s->tlasDataFloats - s->tlasIndexOffset;
+        const uint32_t* T = (const uint32_t*)s->tlasData;
+        const float* inst = (const float*)s->gpuInstances;
+        byLeaf.assign((size_t)indices * 24, 0.0f);
+        for (uint64_t k = 0; k < indices; ++k) {
+            const uint32_t idx = T[s->tlasIndexOffset + k];                 // validated above: < instanceCount
+            memcpy(&byLeaf[k * 24], inst + (size_t)idx * 36 + 16, 20 * sizeof(float));      // worldToLocal + the offsets row
+            memcpy(&byLeaf[k * 24 + 20], &idx, 4);
+        }
+        if ((rc = upload(c, c->instByLeaf, byLeaf.data(), byLeaf.size() * sizeof(float)))) return rc;
+    }
     std::vector<float> cdf;
     float cdfSum = 0.0f;
     if (envOn) {
@@ -614,6 +629,7 @@ int set_scene(PTContext* c, const PTSceneDesc* hostScene, bool validate)
     c->scene.hasTextures = textures ? 1u : 0u;
     c->scene.tlas = tlasOn ? (const float*)c->tlas.ptr : nullptr;
     c->scene.instances = tlasOn ? (const float4*)c->instances.ptr : nullptr;
+    c->scene.instByLeaf = tlasOn ? (const float4*)c->instByLeaf.ptr : nullptr;
     c->scene.tlasIndexOffset = tlasOn ? s->tlasIndexOffset : 0u;
     c->scene.hasTlas = tlasOn ? 1u : 0u;
     c->scene.envTex = envOn ? (const float4*)c->envTex.ptr : nullptr;

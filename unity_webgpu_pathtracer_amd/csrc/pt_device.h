@@ -91,6 +91,8 @@ struct DScene {
     // HAS_TLAS (util/tlas.hlsl): TLASData floats, instance records as 9 x float4 (PTGpuInstance)
     const float*  tlas;
     const float4* instances;
+    const float4* instByLeaf;   // derived by PTSetScene: entry k = worldToLocal (4 rows), offsets row, {instance index} of the instance that TLAS index slot k
+                                // names -- 6 float4, in the order TLAS leaves list them: entering an instance is ONE fetch, not index -> record
     uint32_t tlasIndexOffset;
     uint32_t hasTlas;
     // HAS_ENVIRONMENT_TEXTURE (util/sky.hlsl:7-88): RGBAFloat texels, running sum of their grayscale, its last value

@@ -507,6 +507,10 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(
 #define PT_WF_TLAS_STEPS 0xFFFFFFFFu // TLAS-walk steps a lane between instances takes per wave iteration (0xFFFFFFFF: until it is inside the next instance).
                                      // 200-instance scene, 1080p / 8 spp: unbounded 2,076 Mrays/s, 1 step 1,971, 2 steps 1,889 (round 3)
 #endif
+#ifndef PT_WF_TLAS_CONT
+#define PT_WF_TLAS_CONT 16u          // > 1: a lane keeps walking the TLAS within one wave iteration only while at least this many lanes walk with it
+                                     // (0 / 4 / 8 / 16 / 24 / 32: 2,070 / 2,091 / 2,124 / 2,130 / 2,097 / 2,049 Mrays/s on the 200-instance scene)
+#endif
 #ifndef PT_WF_TLAS_QUORUM
 #define PT_WF_TLAS_QUORUM 0u         // > 0: the TLAS-walk block runs when that many lanes want it, or when no lane is inside an instance (8: 1,920, 16: 1,892)
 #endif
@@ -600,11 +604,21 @@ __global__ __launch_bounds__(64, PT_WF_TLAS_MIN_WAVES) void pt_wf_trace_refill_t
         if (nIdle == 64u) break;
         const uint32_t stopAt = cursor < nItems ? PT_WF_REFILL : 64u;
         do {
+#ifdef PT_TLAS_DIAG
+            // diagnostics builds (tools/experiments/tlas_diag.sh): wave-level event counts / clock ticks through the two pixel counters
+            const bool dl0 = lane == (uint32_t)(__ffsll((long long)__ballot(true)) - 1);
+            if (PT_TLAS_DIAG == 1 && dl0) cn.pixelsWritten++;                                   // outer wave iterations
+            const unsigned long long dT0 = __builtin_readcyclecounter();
+#endif
             // ---- a lane that is between instances (its instance epilogue is done) walks the TLAS to the next instance whose box it hits.
             //      Per ray of the 200-instance scene: 13.0 TLAS nodes + 5.9 instance entries + 9.6 BLAS nodes + 3.0 triangles = 37
-            //      DEPENDENT memory round trips against 18.6 for the same geometry baked flat -- the 1.9x in time.  Rescheduling the
-            //      steps does not shorten that chain: one TLAS step per wave iteration (PT_WF_TLAS_STEPS = 1), a quorum for this block
-            //      and triangle parking (round 2) all measured slower than walking until the lane is inside its next instance.
+            //      steps against 18.6 for the same geometry baked flat.  Measured with the -DPT_TLAS_DIAG builds (tools/experiments/
+            //      tlas_diag.py): this block is 57 % of the loop's time; it runs in 45 % of the wave iterations, 11 inner steps per
+            //      execution (until its slowest lane is inside an instance) at 15.5 of 64 lanes, 80.8 M wave-steps per pass against 16.2 M
+            //      executions of the CWBVH step below (37.8 lanes).  Neither the chain's length (one fetch per instance entry instead
+            //      of two, instByLeaf: no change) nor its scheduling (one TLAS step per wave iteration, a quorum for entering the block,
+            //      triangle parking: all slower) is the lever; letting the last few walkers wait for company (PT_WF_TLAS_CONT) is
+            //      worth 3 %.  What is left is the work itself: 19 TLAS steps per ray at a quarter of the lanes.
             const bool walkT = have && !inBlas;
 #if PT_WF_TLAS_QUORUM > 0
             const uint32_t nWalk = (uint32_t)__popcll(__ballot(walkT)), nIn = (uint32_t)__popcll(__ballot(have && inBlas));
@@ -612,15 +626,27 @@ __global__ __launch_bounds__(64, PT_WF_TLAS_MIN_WAVES) void pt_wf_trace_refill_t
 #else
             const bool runWalk = true;
 #endif
+#ifdef PT_TLAS_DIAG
+            if (PT_TLAS_DIAG == 1 && dl0 && __ballot(walkT && runWalk) != 0ull) cn.pixelsRead++;      // executions of the TLAS-walk block
+            if (PT_TLAS_DIAG == 3 && walkT) cn.pixelsRead++;                                        // lanes entering the walk block
+#endif
             if (walkT && runWalk) {
                 bool finished = false;
                 for (uint32_t stepT = 0; stepT < PT_WF_TLAS_STEPS; ++stepT) {
+                    // the lanes still walking are the wave's active lanes here; when only a few are left they wait for company (the
+                    // lanes whose instance ends in this wave iteration) instead of stepping through the TLAS at 1-2 lanes per instruction
+                    if (PT_WF_TLAS_CONT > 1u && stepT > 0u && (uint32_t)__popcll(__ballot(true)) < PT_WF_TLAS_CONT) break;
+#ifdef PT_TLAS_DIAG
+                    if (PT_TLAS_DIAG == 2) { cn.pixelsRead++; if (lane == (uint32_t)(__ffsll((long long)__ballot(true)) - 1)) cn.pixelsWritten++; }   // lane-steps / wave-steps inside the walk block
+#endif
                     if (instLeft > 0u) {
                         // enter the next instance of the current TLAS leaf (tlas.hlsl:129-147)
-                        instIndex = pt_asuint(T[S.tlasIndexOffset + nextInst]);
+                        // ONE fetch: the record PTSetScene laid out per TLAS index slot (worldToLocal, offsets, instance index) instead of
+                        // TLASData[TLASIndexOffset + k] -> instance record (two dependent fetches; same values)
+                        const float4* ip = S.instByLeaf + (size_t)nextInst * 6;
+                        const float4 w0 = ip[0], w1 = ip[1], w2 = ip[2], w3 = ip[3], ints = ip[4];
+                        instIndex = pt_asuint(ip[5].x);
                         nextInst++; instLeft--;
-                        const float4* ip = S.instances + (size_t)instIndex * 9;
-                        const float4 w0 = ip[4], w1 = ip[5], w2 = ip[6], w3 = ip[7], ints = ip[8];
                         if (STATS) cn.instanceVisits++;
                         nodeOffset = pt_asuint(ints.x); triOffset = pt_asuint(ints.y); attrOffset = pt_asuint(ints.z);
                         const v3 wd = xyz(f4_array(B, 2u * myKind)[2u * (size_t)mySlot + 1u]);           // the direction row of the lane's ray record
@@ -674,6 +700,10 @@ __global__ __launch_bounds__(64, PT_WF_TLAS_MIN_WAVES) void pt_wf_trace_refill_t
                     have = false;
                 }
             }
+#ifdef PT_TLAS_DIAG
+            const unsigned long long dT1 = __builtin_readcyclecounter();
+            if (PT_TLAS_DIAG == 3 && have && inBlas) cn.pixelsWritten++;                             // lanes in the CWBVH step
+#endif
             // ---- the hot step: one CWBVH iteration inside the current instance
             if (have && inBlas) {
                 const float tBefore = rs.hit.t;
@@ -719,6 +749,9 @@ __global__ __launch_bounds__(64, PT_WF_TLAS_MIN_WAVES) void pt_wf_trace_refill_t
                     }
                 }
             }
+#ifdef PT_TLAS_DIAG
+            if (PT_TLAS_DIAG == 4 && dl0) { const unsigned long long dT2 = __builtin_readcyclecounter(); cn.pixelsRead += (uint32_t)((dT1 - dT0) >> 4); cn.pixelsWritten += (uint32_t)((dT2 - dT1) >> 4); }
+#endif
             nIdle = (uint32_t)__popcll(__ballot(!have));
         } while (nIdle < stopAt);
     }
