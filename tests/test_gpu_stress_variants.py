@@ -77,9 +77,10 @@ def test_lds_regrouped_shade_kernel_is_bit_exact(tmp_path):
     default slot-order shade kernel: two progressive passes, frames and all counters identical (textures, all lobes, three light
     types, partially covered edge blocks; HAS_TLAS)."""
     outs = {}
-    for v in ("0", "1"):
+    for v in ("0", "1", "2"):
         out = str(tmp_path / f"sorted{v}.npz")
         subprocess.check_call([sys.executable, "-c", SORTED_CHILD, ROOT, out], env=dict(os.environ, PT_WF_SHADE_SORTED=v), timeout=600)
         outs[v] = np.load(out)
-    for key in outs["0"].files:
-        assert np.array_equal(outs["0"][key].view(np.uint8), outs["1"][key].view(np.uint8)), key
+    for v in ("1", "2"):                                       # 1: regrouped through LDS, 2: pre / hit / post launches over compacted records
+        for key in outs["0"].files:
+            assert np.array_equal(outs["0"][key].view(np.uint8), outs[v][key].view(np.uint8)), (v, key)

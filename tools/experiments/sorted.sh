@@ -1,5 +1,5 @@
 #!/bin/bash
-for v in 0 1; do
+for v in 0 2 1 0 2; do
   PT_WF_SHADE_SORTED=$v python bench.py --schedule 1 --no-extra --no-cpu-baseline --no-alg-replay 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])

@@ -159,7 +159,8 @@ int ensure_wavefront(PTContext* c, PTContext::WfSet& set, uint32_t numSlots, uin
     const bool needTlas = c->scene.hasTlas != 0u;
     set.wf.tailCut = c->tailCut;
     set.wf.shadeSorted = c->shadeSorted;
-    if (set.wf.flags && set.wf.numSlots == numSlots && set.wf.maxIterations >= maxIterations && (!needTlas || set.wf.tlasSpill)) return PT_OK;
+    const bool needRec = c->shadeSorted == 2u;
+    if (set.wf.flags && set.wf.numSlots == numSlots && set.wf.maxIterations >= maxIterations && (!needTlas || set.wf.tlasSpill) && (!needRec || set.wf.recPlanes)) return PT_OK;
     const size_t n = numSlots;
     const uint32_t numRows = 4u * (numSlots >> 6);
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -176,7 +177,7 @@ int ensure_wavefront(PTContext* c, PTContext::WfSet& set, uint32_t numSlots, uin
     const size_t suspBytes = traceWaves * (size_t)(PT_WF_SUSPEND ? PT_WF_SUSPEND : 1u) * 6 * sizeof(uint4);
     const size_t tlasSpillBytes = needTlas ? traceWaves * 64u * (size_t)PT_BVH_STACK_SIZE * sizeof(uint32_t) : 0;
     size_t total = align(n * 4) * 2 + align(n * 16) * PT_F4_COUNT + align(n * 2) + align((size_t)maxIterations * 4 * PT_WF_ALIVE_SHARDS) +
-                   align((size_t)numRows * 16 * 8) + align(8 * 32 * 4) + align(spillBytes) + align(suspBytes) + align(traceWaves * 4) + align(tlasSpillBytes);
+                   align((size_t)numRows * 16 * 8) + align(8 * 32 * 4) + (needRec ? align(n * 16) * 10 + align(n * 4) + align(64) : 0) + align(spillBytes) + align(suspBytes) + align(traceWaves * 4) + align(tlasSpillBytes);
     // The arena only ever grows: a different slot count (another batch size, another frame size) that fits is a new carving of
     // the same memory -- launches already enqueued on the set's stream keep the pointers they were given and finish first
     // (stream order), so neither a synchronisation nor an allocation lands in a caller's timed region.
@@ -205,6 +206,13 @@ int ensure_wavefront(PTContext* c, PTContext::WfSet& set, uint32_t numSlots, uin
     B.stackSpill = (uint2*)carve(spillBytes);
     B.susp = (uint4*)carve(suspBytes);
     B.suspCount = (uint32_t*)carve(traceWaves * 4);
+    B.recPlanes = nullptr; B.recDest = nullptr; B.recCount = nullptr;
+    if (needRec) {
+        B.recPlanes = (float4*)carve(n * 16);
+        for (int k = 1; k < 10; ++k) carve(n * 16);
+        B.recDest = (uint32_t*)carve(n * 4);
+        B.recCount = (uint32_t*)carve(64);
+    }
     B.tlasSpill = needTlas ? (uint32_t*)carve(tlasSpillBytes) : nullptr;
     B.residentWaves = residentWaves;
     B.tailCut = c->tailCut;

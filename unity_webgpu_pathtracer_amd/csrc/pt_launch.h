@@ -91,7 +91,10 @@ struct PTWfBuffers {
     uint4* susp;                // [numSlots / 64][PT_WF_SUSPEND][6]: suspended rays of the refill trace kernel (pt_wavefront.hip)
     uint32_t* suspCount;        // [numSlots / 64]
     uint32_t* aliveFlags;       // [maxIterations][PT_WF_ALIVE_SHARDS] slots still alive after shade launch i of the pass (tail cut, pt_wavefront.hip)
-    uint32_t shadeSorted;       // wavefront shade launches: 1 = pt_wf_shade_sorted (stage 2 regrouped through LDS), 0 = pt_wf_shade (slot order)
+    float4* recPlanes;          // [10][numSlots] shadeSorted == 2: stage-2 records (pt_wf_shade_pre / _hit / _post), float4 planes
+    uint32_t* recDest;          // [numSlots] the record a slot's home lane was given (0xFFFFFFFF: none)
+    uint32_t* recCount;         // [2] records allocated this iteration: surface hits (from the front), misses (from the back)
+    uint32_t shadeSorted;       // wavefront shade launches: 2 = pre / hit / post launches over compacted records, 1 = pt_wf_shade_sorted (stage 2 regrouped through LDS), 0 = pt_wf_shade (slot order)
     uint32_t tailCut;           // later launches of a pass return at once when fewer slots than this are alive; pt_wf_cleanup finishes them
     uint32_t* chunkHeads;       // [8 shards x 32 words]: work counters of the persistent trace kernel, one 128-B line each
     unsigned long long* statRows;   // [numStatRows][16]

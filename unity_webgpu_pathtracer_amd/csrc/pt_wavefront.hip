@@ -1531,6 +1531,196 @@ __global__ __launch_bounds__(256, PT_WF_SHADE_MIN_WAVES) void pt_wf_shade_sorted
     flush_counters<STATS>(cn, B.statRows, blockIdx.x * 4u + wave, lane);
 }
 
+// ------------------------------------------------------------------------------------------
+// shade, split into three launches (round 3, PTWfBuffers.shadeSorted == 2): the regrouping of pt_wf_shade_sorted without its
+// parked waves.  pre: every slot's HOME lane adds the pending NEE (stage 1), and a slot with a closest hit to shade gets a RECORD:
+// rank within the workgroup by ballot + one atomic per workgroup and class for the base (surface hits fill the record array
+// from the front, misses from the back), inputs written as five coalesced float4 planes.  hit: one lane per record, one wave per
+// workgroup -- full waves of surface hits, full waves of misses, nothing idle -- runs path_shade_hit() and writes nine planes of
+// results.  post: the home lanes pick the results up (rank order = slot order inside a workgroup: near-contiguous reads), finish the
+// sample (stage 3) and store the state coalesced.  Which record a slot gets depends on timing; what is computed for it does not.
+// ------------------------------------------------------------------------------------------
+#define PT_SP_PLANES 10u        // float4 planes of the record array (PTWfBuffers.recPlanes, stride numSlots)
+PT_DEV float4* rec_plane(const PTWfBuffers& B, uint32_t k) { return B.recPlanes + (size_t)k * B.numSlots; }
+
+__global__ __launch_bounds__(256) void pt_wf_shade_pre(DScene S, PTWfBuffers B, uint32_t iteration)
+{
+    __shared__ uint32_t s_cnt[2][4];
+    __shared__ uint32_t s_base[2];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint32_t slot = blockIdx.x * 256u + tid;
+    if (blockIdx.x == 0u && tid < PT_WF_SHARDS) B.chunkHeads[tid * 32u] = 0u;   // for the next trace launch (schedule 3)
+    if (tail_cut(B, iteration)) return;
+    const uint32_t f = B.flags[slot];
+    const bool live = fl_state(f) != PS_DONE;
+    uint32_t key = 2u;
+    uint32_t rng = 0u;
+    float4 qro = make_float4(0, 0, 0, 0), qrd = qro, qrad = qro, qthr = qro, qhit = qro, qhit2 = qro;
+    if (live) {
+        const bool pending = fl_pending(f);
+        qrad = B.rad[slot];
+        qhit = B.hit[slot];
+        if (pending) {
+            const float4 qenvC = B.envC[slot], qlightC = B.lightC[slot], qpthr = B.pthr[slot];
+            const uint32_t o0 = B.occl[slot], o1 = B.occl[(size_t)B.numSlots + slot];
+            PathRegs r;
+            r.hasPending = true;
+            r.env.valid = fl_env(f); r.light.valid = fl_light(f);
+            r.green = (f >> 6) & 1u;
+            r.radiance = xyz(qrad);
+            r.env.contribution = xyz(qenvC); r.light.contribution = xyz(qlightC); r.pendThroughput = xyz(qpthr);
+            path_apply_pending(r, o0 != 0u, o1 != 0u);
+            qrad = f4(r.radiance, 0.0f);
+            B.rad[slot] = qrad;                                       // stage 3 (and a slot that skips stage 2) reads it back
+        }
+        if (fl_state(f) == PS_TRACE) {
+            key = qhit.x < PT_FAR_PLANE ? 0u : 1u;
+            rng = B.rng[slot];
+            qro = B.ray[0][2u * slot]; qrd = B.ray[0][2u * slot + 1u]; qthr = B.thr[slot];
+            if (S.hasTlas) qhit2 = B.hit2[slot];
+        }
+    }
+    const unsigned long long m0 = __ballot(key == 0u), m1 = __ballot(key == 1u);
+    if (lane == 0u) { s_cnt[0][wave] = (uint32_t)__popcll(m0); s_cnt[1][wave] = (uint32_t)__popcll(m1); }
+    __syncthreads();
+    uint32_t base0 = 0u, base1 = 0u, total0 = 0u, total1 = 0u;
+#pragma unroll
+    for (uint32_t w = 0; w < 4u; ++w) {
+        const uint32_t c0 = s_cnt[0][w], c1 = s_cnt[1][w];
+        if (w < wave) { base0 += c0; base1 += c1; }
+        total0 += c0; total1 += c1;
+    }
+    if (tid == 0u) {
+        s_base[0] = total0 ? atomicAdd(&B.recCount[0], total0) : 0u;
+        s_base[1] = total1 ? atomicAdd(&B.recCount[1], total1) : 0u;
+    }
+    __syncthreads();
+    uint32_t dest = 0xFFFFFFFFu;
+    if (key == 0u) dest = s_base[0] + base0 + rank_below(m0);
+    else if (key == 1u) dest = B.numSlots - 1u - (s_base[1] + base1 + rank_below(m1));      // misses fill the array from the back
+    if (live) B.recDest[slot] = dest;
+    if (dest != 0xFFFFFFFFu) {
+        rec_plane(B, 0)[dest] = qro;                                  // origin, scatterPdf
+        rec_plane(B, 1)[dest] = qrd;                                  // direction, maxRoughness
+        rec_plane(B, 2)[dest] = make_float4(qthr.x, qthr.y, qthr.z, pt_asfloat(rng));
+        rec_plane(B, 3)[dest] = make_float4(qrad.x, qrad.y, qrad.z, pt_asfloat(f >> 19));     // radiance, depth
+        rec_plane(B, 4)[dest] = qhit;
+        if (S.hasTlas) rec_plane(B, 5)[dest] = qhit2;
+        B.pthr[slot] = qthr;                                          // the throughput the NEE of this bounce applies to (if it produces one)
+    }
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(64, PT_WF_SHADE_MIN_WAVES) void pt_wf_shade_hit(DScene S, PTFrameParams P, PTWfBuffers B, uint32_t iteration)
+{
+    if (tail_cut(B, iteration)) return;
+    const uint32_t idx = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t c0 = B.recCount[0], c1 = B.recCount[1];
+    const bool mine = idx < c0 || idx >= B.numSlots - c1;
+    Counters cn = {};
+    if (mine) {
+        const float4 p0 = rec_plane(B, 0)[idx], p1 = rec_plane(B, 1)[idx], p2 = rec_plane(B, 2)[idx], p3 = rec_plane(B, 3)[idx], p4 = rec_plane(B, 4)[idx];
+        PathRegs w;
+        w.ro = xyz(p0); w.scatterPdf = p0.w;
+        w.rd = xyz(p1); w.maxRoughness = p1.w;
+        w.throughput = xyz(p2); w.rng = pt_asuint(p2.w);
+        w.radiance = xyz(p3); w.depth = pt_asuint(p3.w);
+        HitRecord ch;
+        ch.h.t = p4.x; ch.h.u = p4.y; ch.h.v = p4.z; ch.h.triIndex = pt_asuint(p4.w);
+        ch.pos = mk3(0.0f); ch.inst = 0u;
+        if (S.hasTlas) { const float4 p5 = rec_plane(B, 5)[idx]; ch.pos = xyz(p5); ch.inst = pt_asuint(p5.w); }
+        w.state = PS_TRACE; w.hasPending = false; w.green = false; w.sampleIdx = 0u;
+        w.color = mk3(0.0f);
+        w.env.valid = 0u; w.light.valid = 0u;
+        w.env.dir = mk3(0.0f); w.light.dir = mk3(0.0f); w.neeOrigin = mk3(0.0f);
+        w.env.contribution = mk3(0.0f); w.light.contribution = mk3(0.0f); w.pendThroughput = mk3(0.0f);
+        struct Sink {                                                // the NEE rays of the bounce leave for their planes as soon as they are final
+            const PTWfBuffers& B; uint32_t i;
+            PT_DEV void operator()(PathRegs& q) const {
+                uint32_t j = i;
+                asm volatile("" : "+v"(j));
+                rec_plane(B, 5)[j] = f4(q.neeOrigin, 0.0f);
+                rec_plane(B, 6)[j] = f4(q.env.dir, 0.0f);
+                rec_plane(B, 7)[j] = f4(q.light.dir, 0.0f);
+                rec_plane(B, 8)[j] = f4(q.env.contribution, 0.0f);
+                rec_plane(B, 9)[j] = f4(q.light.contribution, 0.0f);
+            }
+        };
+        path_shade_hit<STATS, Sink>(S, P, w, ch, cn, Sink{B, idx});
+        uint32_t j = idx;
+        asm volatile("" : "+v"(j));
+        rec_plane(B, 0)[j] = f4(w.ro, w.scatterPdf);
+        rec_plane(B, 1)[j] = f4(w.rd, w.maxRoughness);
+        rec_plane(B, 2)[j] = make_float4(w.throughput.x, w.throughput.y, w.throughput.z, pt_asfloat(w.rng));
+        rec_plane(B, 3)[j] = make_float4(w.radiance.x, w.radiance.y, w.radiance.z,
+                                         pt_asfloat((w.state & 3u) | ((w.hasPending ? 1u : 0u) << 2) | ((w.env.valid & 3u) << 3) | ((w.light.valid & 1u) << 5) |
+                                                    ((w.green ? 1u : 0u) << 6) | ((w.depth & 0x1FFFu) << 19)));
+    }
+    flush_counters<STATS>(cn, B.statRows, blockIdx.x, threadIdx.x);
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(256) void pt_wf_shade_post(PTFrameParams P, PTTileMap tm, PTWfBuffers B, uint32_t iteration)
+{
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint32_t slot = blockIdx.x * 256u + tid;
+    if (blockIdx.x == 0u && tid < 2u) B.recCount[tid] = 0u;           // for the next iteration's pre launch (this launch does not read them)
+    if (tail_cut(B, iteration)) return;
+    Counters cn = {};
+    const uint32_t f = B.flags[slot];
+    bool alive = false;
+    if (fl_state(f) != PS_DONE) {
+        uint32_t px, py, pass;
+        pt_slot_to_pixel(tm, pixel_slot_of(B, slot, pass), px, py);
+        const uint32_t dest = B.recDest[slot];
+        PathRegs r;
+        r.sampleIdx = (f >> 7) & 0xFFFu;
+        r.color = xyz(B.color[slot]);
+        r.env.dir = mk3(0.0f); r.light.dir = mk3(0.0f); r.neeOrigin = mk3(0.0f);
+        r.env.contribution = mk3(0.0f); r.light.contribution = mk3(0.0f); r.pendThroughput = mk3(0.0f);
+        r.env.valid = 0u; r.light.valid = 0u;
+        bool writeNee = false;
+        if (dest != 0xFFFFFFFFu) {
+            const float4 q0 = rec_plane(B, 0)[dest], q1 = rec_plane(B, 1)[dest], q2 = rec_plane(B, 2)[dest], q3 = rec_plane(B, 3)[dest];
+            const uint32_t m = pt_asuint(q3.w);
+            r.state = m & 3u; r.hasPending = (m >> 2) & 1u; r.env.valid = (m >> 3) & 3u; r.light.valid = (m >> 5) & 1u; r.green = (m >> 6) & 1u;
+            r.depth = m >> 19;
+            r.ro = xyz(q0); r.scatterPdf = q0.w;
+            r.rd = xyz(q1); r.maxRoughness = q1.w;
+            r.throughput = xyz(q2); r.rng = pt_asuint(q2.w);
+            r.radiance = xyz(q3);
+            if (r.hasPending) {
+                writeNee = true;
+                r.neeOrigin = xyz(rec_plane(B, 5)[dest]);
+                r.env.dir = xyz(rec_plane(B, 6)[dest]);
+                r.light.dir = xyz(rec_plane(B, 7)[dest]);
+                r.env.contribution = xyz(rec_plane(B, 8)[dest]);
+                r.light.contribution = xyz(rec_plane(B, 9)[dest]);
+                r.pendThroughput = xyz(B.pthr[slot]);
+            }
+        } else {
+            // no closest hit to shade: the path was waiting for its last NEE (state ENDING, radiance updated by the pre launch)
+            r.state = fl_state(f); r.hasPending = false; r.green = false;
+            r.depth = f >> 19;
+            r.radiance = xyz(B.rad[slot]);
+            r.rng = B.rng[slot];
+            const float4 qro = B.ray[0][2u * slot], qrd = B.ray[0][2u * slot + 1u], qthr = B.thr[slot];
+            r.ro = xyz(qro); r.scatterPdf = qro.w;
+            r.rd = xyz(qrd); r.maxRoughness = qrd.w;
+            r.throughput = xyz(qthr);
+        }
+        path_end_sample<false>(P, r, px, py, py * P.OutputWidth + px, nullptr, nullptr, cn);
+        store_path(B, slot, r, writeNee);
+        alive = r.state != PS_DONE;
+    }
+    {
+        const uint32_t nAlive = (uint32_t)__popcll(__ballot(alive));
+        if (B.tailCut != 0u && nAlive && lane == 0u)
+            atomicAdd(&B.aliveFlags[iteration * PT_WF_ALIVE_SHARDS + (blockIdx.x & (PT_WF_ALIVE_SHARDS - 1u))], nAlive);
+    }
+    flush_counters<STATS>(cn, B.statRows, blockIdx.x * 4u + wave, lane);
+}
+
 // cleanup: pixels still alive after the fixed number of iterations are run to completion here, one lane per slot with
 // the megakernel's loop (trace <= 3 rays, path_step, repeat).  Normally a handful of lanes; correctness for any path length.
 template <bool STATS, bool TLAS>
@@ -1687,6 +1877,7 @@ hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const PT
         return hipGetLastError();
     }
     if ((e = hipMemsetAsync(B.aliveFlags, 0, sizeof(uint32_t) * B.maxIterations * PT_WF_ALIVE_SHARDS, stream)) != hipSuccess) return e;
+    if (B.shadeSorted == 2u && (e = hipMemsetAsync(B.recCount, 0, 2 * sizeof(uint32_t), stream)) != hipSuccess) return e;
     hipLaunchKernelGGL(pt_wf_init, dim3(nb), dim3(256), 0, stream, P, batch, tm, B);
     launches++;
     const uint32_t spp = P.SamplesPerPass > 1 ? (uint32_t)P.SamplesPerPass : 1u;
@@ -1733,7 +1924,17 @@ hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const PT
             if (fullStats) hipLaunchKernelGGL((pt_wf_trace<true, false>), dim3(nb * 3u), dim3(256), 0, stream, S, B, it);
             else hipLaunchKernelGGL((pt_wf_trace<false, false>), dim3(nb * 3u), dim3(256), 0, stream, S, B, it);
         }
-        if (B.shadeSorted) {
+        if (B.shadeSorted == 2u) {
+            hipLaunchKernelGGL(pt_wf_shade_pre, dim3(nb), dim3(256), 0, stream, S, B, it);
+            if (fullStats) {
+                hipLaunchKernelGGL(pt_wf_shade_hit<true>, dim3(B.numSlots / 64u), dim3(64), 0, stream, S, P, B, it);
+                hipLaunchKernelGGL(pt_wf_shade_post<true>, dim3(nb), dim3(256), 0, stream, P, tm, B, it);
+            } else {
+                hipLaunchKernelGGL(pt_wf_shade_hit<false>, dim3(B.numSlots / 64u), dim3(64), 0, stream, S, P, B, it);
+                hipLaunchKernelGGL(pt_wf_shade_post<false>, dim3(nb), dim3(256), 0, stream, P, tm, B, it);
+            }
+            launches += 2;
+        } else if (B.shadeSorted) {
             if (fullStats) hipLaunchKernelGGL(pt_wf_shade_sorted<true>, dim3(nb), dim3(256), 0, stream, S, P, tm, B, it);
             else hipLaunchKernelGGL(pt_wf_shade_sorted<false>, dim3(nb), dim3(256), 0, stream, S, P, tm, B, it);
         } else {
