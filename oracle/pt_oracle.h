@@ -59,6 +59,11 @@ int oracle_render(const PTSceneDesc* scene, const PTFrameParams* params, const f
 int oracle_trace(const PTSceneDesc* scene, const OracleRay* rays, uint64_t n, float* outT,
                  uint32_t* outPrim, uint32_t* outSteps);
 
+/* The same traversal reporting the full closest-hit record per ray: out4[i] = {t, u, v, primitive bits} (0xFFFFFFFF, u = v = 0 on a
+ * miss), and the node visits / triangle tests of the batch.  Compared bit for bit with the reference's own CWBVH walker
+ * (BVH8_CWBVH::Intersect, tiny_bvh.h:7006-7114; oracle/ref_driver_cwbvh.cpp) by tests/test_oracle.py. */
+int oracle_trace_uv(const PTSceneDesc* scene, const OracleRay* rays, uint64_t n, float* out4, uint64_t* outNodeVisits, uint64_t* outTriTests);
+
 /* Scalar entry points for unit tests. */
 float    oracle_random_float(uint32_t* state);                       /* util/random.hlsl:12-16 */
 float    oracle_math(int fn, float x, float y);                      /* ptmi_math.h: 0 sin 1 cos 2 log 3 log2 4 exp2 5 pow 6 acos 7 asin 8 sqrt 9 rcp 10 atan2(x = y-arg, y = x-arg) 11 fmod 12 wrap01 (closed form) 13 wrap01 (literal loops) */
@@ -66,6 +71,10 @@ float    oracle_math(int fn, float x, float y);                      /* ptmi_mat
  * material: 32 floats of MaterialData (no textures); V, N, L world-space; returns f via out[0..2], pdf out[3]. */
 void     oracle_eval_brdf(const float* material, const float* V, const float* N, const float* L, float eta, float* out);
 void     oracle_sample_brdf(const float* material, const float* V, const float* N, float eta, uint32_t* rngState, float* outL, float* outFPdf);
+/* Batch forms for the distribution tests (per lobe: pdf integrates to the probability of a usable sample; samples follow the pdf):
+ * L: n x 3 -> out: n x 4; n consecutive SampleBRDF calls on ONE RNG chain -> outL: n x 3, outFPdf: n x 4. */
+void     oracle_eval_brdf_batch(const float* material, const float* V, const float* N, float eta, const float* L, uint64_t n, float* out);
+void     oracle_sample_brdf_batch(const float* material, const float* V, const float* N, float eta, uint32_t* rngState, uint64_t n, float* outL, float* outFPdf);
 
 /* Environment-texture functions in isolation (util/sky.hlsl:7-88), `scene` with HAS_ENVIRONMENT_TEXTURE:
  *   what 0: EnvironmentCDF[i] for i = in[k] (as float index)            -> out[k]            (n values)
@@ -73,9 +82,6 @@ void     oracle_sample_brdf(const float* material, const float* V, const float* 
  *   what 2: EvalEnvMap(in[3k..3k+2], intensity 1)                       -> out[4k..4k+3]     (rgb, pdf)
  *   what 3: SampleEnvMap with rngState = (uint)in[k] bits               -> out[8k..8k+7]     (dir xyz, pdf, colour rgb, 0)
  * Returns EnvironmentCdfSum. */
-int oracle_trace_uv(const PTSceneDesc* scene, const OracleRay* rays, uint64_t n, float* out4, uint64_t* outNodeVisits, uint64_t* outTriTests);
-void oracle_eval_brdf_batch(const float* material, const float* V, const float* N, float eta, const float* L, uint64_t n, float* out);
-void oracle_sample_brdf_batch(const float* material, const float* V, const float* N, float eta, uint32_t* rngState, uint64_t n, float* outL, float* outFPdf);
 float    oracle_env_probe(const PTSceneDesc* scene, const PTFrameParams* params, int what, const float* in, uint64_t n, float* out);
 
 /* Scene ingestion: one Dispatch of MeshProcessing.compute:59-139 (writes triangles [OutputTriangleStart, +TriangleCount) of both
