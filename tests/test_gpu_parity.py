@@ -241,6 +241,8 @@ def test_pass_batch_equals_sequential_passes(schedule):
         b = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
         pt.render_batch_to(params[0:3], a.data_ptr(), 0)             # passes 0-2
         pt.render_batch_to(params[3:4], b.data_ptr(), a.data_ptr())  # a batch of one
+        if schedule == 1:
+            pt.set_sub_frames(2)                                      # batches and sub-frames together: 2 launch sequences x 3 passes
         pt.render_batch_to(params[4:7], a.data_ptr(), b.data_ptr())  # passes 4-6, accumulated frame given
         pt.synchronize()
         got = a.cpu().numpy()
