@@ -262,13 +262,16 @@ def main():
                 k += n
             return cur
 
-        if args.batch > 1:
-            # untimed priming, not a step: one FULL batch, so that the state sets are allocated for the largest launch sequence of
-            # the run before the warm-up (whose last group may be shorter); pass 0 of the warm-up overwrites the frame it leaves
-            ps0 = [scenes.frame_params(scene, W, H, spp=SPP, current_sample=0, seed=seed_of(1000 + j), max_bounces=args.bounces) for j in range(args.batch)]
-            for _ in range(max(1, pt.passes_in_flight())):
+        # untimed priming, not steps: every state set the timed region will use is allocated and touched (one full batch each),
+        # and the GPU has left its idle clocks (the first run on a fresh box used to read up to 15 % low); pass 0 of the warm-up
+        # overwrites the frame this leaves
+        ps0 = [scenes.frame_params(scene, W, H, spp=SPP, current_sample=0, seed=seed_of(1000 + j), max_bounces=args.bounces) for j in range(max(1, args.batch))]
+        for _ in range(max(12, pt.passes_in_flight()) if full else 2):
+            if len(ps0) > 1:
                 pt.render_batch_to(ps0, frames[0].data_ptr(), 0)
-            sync_all()
+            else:
+                pt.render_pass_to(ps0[0], frames[0].data_ptr(), 0)
+        sync_all()
         cur = run_steps(0, warmup, 0)
         sync_all()
         pt.reset_stats()
