@@ -590,16 +590,35 @@ PT_DEV void derive_light_rows(const DLight& light, float4 rows[4])
     rows[3] = make_float4(nn.x, nn.y, nn.z, 0.0f);
 }
 
+// A WAVE-UNIFORM read of scene constants (the light records every lane of a wave walks through in the same order): through the
+// constant address space the compiler emits scalar loads (s_load_dwordx4 into SGPRs, served by the scalar cache) instead of 64
+// identical lane requests on the vector-memory path -- which costs a broadcast as much as a gather (~55 CU-cycles per instruction,
+// tools/microbench/gather16.hip) and parks the result in VGPRs.  Round 3: the light loop of intersect_lights issued ~5 such loads per
+// light and shading step, ~6 x 10^8 lane requests per Sponza-class pass, a tenth of all vector-memory requests.
+#ifndef PT_UNIFORM_LIGHTS
+#define PT_UNIFORM_LIGHTS 0          // scenes with at most this many lights read all of them per wave (scalar loads) in nee_prepare_light.
+                                     // Measured with 4 on the two-light Sponza-class scene: 5,088 against 5,102 Mrays/s with 0 (the per-lane gather): off
+#endif
+typedef float pt_vec4 __attribute__((ext_vector_type(4)));
+PT_DEV float4 pt_uniform_load(const float4* p, size_t index)          // p + index must be the same address in every lane of the wave
+{
+    const __attribute__((address_space(4))) pt_vec4* q = (const __attribute__((address_space(4))) pt_vec4*)(uintptr_t)p;
+    const pt_vec4 v = q[index];
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 template <bool STATS>
 PT_DEV void intersect_lights(const DScene& S, v3 o, v3 d, SurfHit& hit, Counters& cn)
 {
     if (!S.hasLights) return;
     for (int i = 0; i < S.lightCount; ++i) {
-        DLight light = load_light(S, i);
+        const float4 la = pt_uniform_load(S.lights, (size_t)i * 4);                  // i is wave-uniform
+        DLight light;
+        light.position = mk3(la.x, la.y, la.z); light.type = pt_asuint(la.w);
         if (STATS) cn.lightFetches++;
         if (light.type == PT_LIGHT_TYPE_RECTANGLE) {
-            const float4* lc = S.lightConst + (size_t)i * 4;
-            const float4 c0 = lc[0], c1 = lc[1], c2 = lc[2];
+            const float4 c0 = pt_uniform_load(S.lightConst, (size_t)i * 4), c1 = pt_uniform_load(S.lightConst, (size_t)i * 4 + 1),
+                         c2 = pt_uniform_load(S.lightConst, (size_t)i * 4 + 2);
             v3 normal = mk3(c0.x, c0.y, c0.z);                   // normalize(cross(light.u, light.v))
             float planeW = c0.w;                                 // dot(normal, light.position)
             v3 u = mk3(c1.x, c1.y, c1.z);                        // light.u / dot(light.u, light.u)
@@ -1174,9 +1193,29 @@ PT_DEV void nee_prepare_light(const DScene& S, v3 rayDir, const SurfHit& hit, co
     if (!S.hasLights) return;
     int32_t lightIndex = pt_f2i(rnd(rng) * (float)S.lightCount);
     if (lightIndex > S.lightCount - 1) lightIndex = S.lightCount - 1;
-    DLight light = load_light(S, lightIndex);
+    // The picked light differs from lane to lane, but with a handful of lights it is cheaper to read EVERY light once per wave
+    // through the scalar path (pt_uniform_load) and keep the lane's own than to gather six rows per lane: no vector-memory
+    // requests, no dependent round trip in front of the BSDF evaluation.  Same records, same values.
+    DLight light;
+    float4 lcN, lcNN;
+    if (S.lightCount <= PT_UNIFORM_LIGHTS) {
+        float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = a, c = a, d = a;
+        lcN = a; lcNN = a;
+        for (int i = 0; i < S.lightCount; ++i) {
+            const float4 ua = pt_uniform_load(S.lights, (size_t)i * 4), ub = pt_uniform_load(S.lights, (size_t)i * 4 + 1),
+                         uc = pt_uniform_load(S.lights, (size_t)i * 4 + 2), ud = pt_uniform_load(S.lights, (size_t)i * 4 + 3),
+                         un = pt_uniform_load(S.lightConst, (size_t)i * 4), unn = pt_uniform_load(S.lightConst, (size_t)i * 4 + 3);
+            if (lightIndex == i) { a = ua; b = ub; c = uc; d = ud; lcN = un; lcNN = unn; }
+        }
+        light.position = mk3(a.x, a.y, a.z); light.type = pt_asuint(a.w);
+        light.emission = mk3(b.x, b.y, b.z); light.range = b.w;
+        light.u = mk3(c.x, c.y, c.z); light.area = c.w;
+        light.v = mk3(d.x, d.y, d.z);
+    } else {
+        light = load_light(S, lightIndex);
+        lcN = S.lightConst[(size_t)lightIndex * 4]; lcNN = S.lightConst[(size_t)lightIndex * 4 + 3];
+    }
     if (STATS) cn.lightFetches++;
-    const float4 lcN = S.lightConst[(size_t)lightIndex * 4], lcNN = S.lightConst[(size_t)lightIndex * 4 + 3];
     v3 lsNormal, lsDirection;
     float lsDistance, lsPdf;
     if (light.type == PT_LIGHT_TYPE_SPOT) {
