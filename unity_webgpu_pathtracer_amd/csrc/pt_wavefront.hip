@@ -205,6 +205,11 @@ static_assert(PT_WF_RANGE >= 64u && (PT_WF_RANGE & (PT_WF_RANGE - 1u)) == 0u,
 #define PT_WF_TRI_PARK 4u       // > 0: two-phase wave iteration (ray_tri_one / ray_node_one); lanes with triangles pending wait until
                                 // that many lanes do.  0: ray_step's nested loops.  2 ... 12 measure the same (+6 %), 16: +3 %, 24: -2 %
 #endif
+#ifndef PT_WF_ROOT_SCALAR
+#define PT_WF_ROOT_SCALAR 0     // 1: main refill launch reads the root node once per wave through the scalar path and visits it when a ray is taken.
+                                // Measured: 4,918 / 4,938 against 5,090 / 5,063 Mrays/s -- 4.5e8 lane requests and one dependent fetch per ray saved, but the
+                                // node test then runs in the refill block at 25-50 % of the lanes (round 2's LDS copy of the root lost the same way)
+#endif
 #ifndef PT_WF_HIT_REGS
 #define PT_WF_HIT_REGS 1        // main refill launch (with PT_WF_TRI_PARK): the hit's (u, v, triIndex) stay in registers until the ray ends
 #endif
@@ -318,6 +323,18 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(
     st.stride = 64u;
     st.gbase = B.stackSpill;
     st.gwave = PT_LDS_WORD(s_gw);                                                 // slab row = wave * 64 + lane < numSlots
+#if PT_WF_ROOT_SCALAR
+    uint4 root0 = make_uint4(0u, 0u, 0u, 0u), root1 = root0, root2 = root0, root3 = root0, root4 = root0;
+    if (!TAIL) {
+        const float4 r0 = pt_uniform_load((const float4*)S.nodes, 0), r1 = pt_uniform_load((const float4*)S.nodes, 1), r2 = pt_uniform_load((const float4*)S.nodes, 2),
+                     r3 = pt_uniform_load((const float4*)S.nodes, 3), r4 = pt_uniform_load((const float4*)S.nodes, 4);
+        root0 = make_uint4(pt_asuint(r0.x), pt_asuint(r0.y), pt_asuint(r0.z), pt_asuint(r0.w));
+        root1 = make_uint4(pt_asuint(r1.x), pt_asuint(r1.y), pt_asuint(r1.z), pt_asuint(r1.w));
+        root2 = make_uint4(pt_asuint(r2.x), pt_asuint(r2.y), pt_asuint(r2.z), pt_asuint(r2.w));
+        root3 = make_uint4(pt_asuint(r3.x), pt_asuint(r3.y), pt_asuint(r3.z), pt_asuint(r3.w));
+        root4 = make_uint4(pt_asuint(r4.x), pt_asuint(r4.y), pt_asuint(r4.z), pt_asuint(r4.w));
+    }
+#endif
     RayState rs;
     rs.sp = 0u; rs.anyHit = false; rs.overflow = false;
     bool have = false;
@@ -355,7 +372,18 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(
                         // NaN ray: certain miss
                         if (myKind == 0u) store_miss(B, mySlot);
                         else store_occlusion(B, myKind, mySlot, false);
-                    } else have = true;
+                    } else {
+                        have = true;
+#if PT_WF_ROOT_SCALAR
+                        // Every ray's first node visit is the ROOT (ray_begin leaves the node group (0, bit 31): child 0 of base 0): the
+                        // same five rows for every lane.  They are read once per wave through the scalar path (root0..root4) and the
+                        // visit happens here, at refill time: ~9 x 10^7 rays x 5 rows per pass leave the vector-memory path and every
+                        // ray's chain of dependent fetches is one shorter.  Same operations per ray: cwbvh_pick_child (nothing to push:
+                        // the group holds one child) + cwbvh_apply_node.
+                        rs.ng.y = 0u;                                                       // the root taken off its node group
+                        cwbvh_apply_node<STATS>(rs.o, rs.invDir, rs.octinv4, rs.hit.t, root0, root1, root2, root3, root4, rs.ng, rs.tg, cn);
+#endif
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();
                 cursor += consumed;
