@@ -54,20 +54,21 @@ def per_pass(rows, value_of):
     return [total / n_pass] * n_pass, {k: v / n_pass for k, v in per_kernel.items()}
 
 
-def regime_summary(rows, regime, warmup=5):
+def regime_summary(rows, regime, timed=20):
     """Span-based time per pass of a kernel trace: a pass is complete when its pt_wf_resolve (or pt_megakernel) ends; the steady
-    figure is (end of the last pass - end of the last WARM-UP pass) / timed passes -- what bench.py's HIP events measure.  Also the
-    sum of kernel durations per pass and the mean number of kernels running at once (sum / span)."""
+    figure is (end of the last pass - end of the last pass BEFORE the timed ones) / timed passes -- what bench.py's HIP events
+    measure (the trace also holds bench.py's untimed priming and warm-up passes).  Also the sum of kernel durations per pass and the
+    mean number of kernels running at once (sum / span), both over the timed passes only."""
     ends = sorted(int(r["End_Timestamp"]) for r in rows if "pt_wf_resolve" in r["Kernel_Name"] or "pt_megakernel" in r["Kernel_Name"])
-    t0 = min(int(r["Start_Timestamp"]) for r in rows)
-    t1 = max(int(r["End_Timestamp"]) for r in rows)
-    busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows)
     n = len(ends)
-    res = {"regime": regime, "passes": n, "span_ms": (t1 - t0) / 1e6, "sum_of_kernel_ms_per_pass": busy / 1e6 / max(1, n),
-           "mean_kernels_in_flight": busy / max(1, t1 - t0)}
-    if n > warmup:
-        res["steady_ms_per_pass"] = (ends[-1] - ends[warmup - 1]) / 1e6 / (n - warmup)
-        res["steady_note"] = f"(end of pass {n} - end of warm-up pass {warmup}) / {n - warmup} timed passes"
+    res = {"regime": regime, "passes": n}
+    if n > timed:
+        t0, t1 = ends[-1 - timed], ends[-1]
+        # kernels of the timed region: everything that ends after the last untimed pass has completed (bench.py synchronises there)
+        busy = sum(int(r["End_Timestamp"]) - max(int(r["Start_Timestamp"]), t0) for r in rows if int(r["End_Timestamp"]) > t0)
+        res.update({"timed_passes": timed, "span_ms": (t1 - t0) / 1e6, "steady_ms_per_pass": (t1 - t0) / 1e6 / timed,
+                    "sum_of_kernel_ms_per_pass": busy / 1e6 / timed, "mean_kernels_in_flight": busy / max(1, t1 - t0),
+                    "steady_note": f"(end of pass {n} - end of pass {n - timed}) / {timed} timed passes"})
     return {"trace": res}
 
 
@@ -108,7 +109,7 @@ def main():
         per = {}
         for r in rows:
             per.setdefault(short(r["Kernel_Name"]), []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
-        n = max(1, ser["trace"]["passes"])
+        n = max(1, ser["trace"]["passes"])                                       # per-kernel means over ALL passes of the run (they run alone either way)
         ser["kernel_ms"] = {k: {"calls_per_pass": len(v) / n, "mean": sum(v) / len(v), "total_per_pass": sum(v) / n} for k, v in per.items()}
         out["serialised"] = ser
         st = newest(os.path.join(base, f"{tag}_serial", "*", "*_kernel_stats.csv"))
