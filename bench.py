@@ -266,7 +266,7 @@ def main():
         # and the GPU has left its idle clocks (the first run on a fresh box used to read up to 15 % low); pass 0 of the warm-up
         # overwrites the frame this leaves
         ps0 = [scenes.frame_params(scene, W, H, spp=SPP, current_sample=0, seed=seed_of(1000 + j), max_bounces=args.bounces) for j in range(max(1, args.batch))]
-        for _ in range(max(12, pt.passes_in_flight()) if full else 2):
+        for _ in range(max(12, pt.passes_in_flight())):
             if len(ps0) > 1:
                 pt.render_batch_to(ps0, frames[0].data_ptr(), 0)
             else:
