@@ -229,6 +229,7 @@ PT_API int PTGroupSize(PTGroup* group);
 PT_API PTContext* PTGroupGetContext(PTGroup* group, int index);      /* for PTSetSchedule / PTSetStatsLevel / ... per device */
 PT_API int PTGroupSetScene(PTGroup* group, const PTSceneDesc* scene);
 PT_API int PTGroupRenderPass(PTGroup* group, const PTFrameParams* params);
+PT_API int PTGroupRenderPassBatch(PTGroup* group, const PTFrameParams* params, int count);   /* `count` passes per device as one launch sequence (PTRenderPassBatch), one assembly */
 PT_API int PTGroupFlipFrames(PTGroup* group);
 PT_API int PTGroupResetFrames(PTGroup* group);
 PT_API int PTGroupSynchronize(PTGroup* group);
@@ -258,6 +259,9 @@ PT_API int PTRenderPassTo(PTContext* ctx, const PTFrameParams* params, void* dOu
  * pass is too small a launch to fill an MI355X: eight passes of a 1/8 share are one whole frame's worth of paths.  PTStats counts
  * pixelsWritten / pixelsRead as the `count` separate passes would. */
 PT_API int PTRenderPassBatchTo(PTContext* ctx, const PTFrameParams* params, int count, void* dOutput, const void* dAccumulated);
+/* The same over the context's internal frame pair: Output = the current frame, AccumulatedOutput = the other one, as PTRenderPass;
+ * the caller advances _currentSample by count x SamplesPerPass and flips ONCE (the intermediate frames do not exist). */
+PT_API int PTRenderPassBatch(PTContext* ctx, const PTFrameParams* params, int count);
 
 /* Block until every pass launched so far has finished. */
 PT_API int PTSynchronize(PTContext* ctx);

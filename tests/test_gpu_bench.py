@@ -90,6 +90,9 @@ def test_group_api_two_contexts_one_device_matches_single_gpu():
         assert zlib.crc32(got.tobytes()) == zlib.crc32(ref.tobytes())
         assert st.rays == ref_stats.rays and st.paths == ref_stats.paths and st.pixelsWritten == ref_stats.pixelsWritten
         grp.Reset()
+        grp.OnRenderBatch(seeds)                                   # the two passes as ONE launch sequence per device, one assembly
+        assert np.array_equal(grp.readback().view(np.uint32), ref.view(np.uint32)), devices
+        grp.Reset()
         grp.OnRenderImage(seeds[0])                                # Reset(): the first pass again gives the first frame again
         again = grp.readback()
         grp.close()

@@ -678,6 +678,19 @@ PT_API int PTRenderPass(PTContext* c, const PTFrameParams* hostParams)
     return render_to(c, p, c->frames[c->cur], c->frames[1 - c->cur]);
 }
 
+PT_API int PTRenderPassBatchTo(PTContext* c, const PTFrameParams* hostParams, int count, void* dOutput, const void* dAccumulated);
+
+PT_API int PTRenderPassBatch(PTContext* c, const PTFrameParams* hostParams, int count)
+{
+    if (!c || !hostParams) return fail(PT_ERR_INVALID_ARG, "ctx/params == NULL");
+    PTFrameParams params;
+    int rc = import_params(hostParams, params);
+    if (rc || (rc = validate_params(&params))) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    if ((rc = ensure_frames(c, params.OutputWidth, params.OutputHeight))) return rc;
+    return PTRenderPassBatchTo(c, hostParams, count, c->frames[c->cur], c->frames[1 - c->cur]);
+}
+
 PT_API int PTFlipFrames(PTContext* c) { if (!c) return fail(PT_ERR_INVALID_ARG, "ctx == NULL"); c->cur = 1 - c->cur; return PT_OK; }
 PT_API int PTResetFrames(PTContext* c) { if (!c) return fail(PT_ERR_INVALID_ARG, "ctx == NULL"); c->cur = 0; return PT_OK; }
 
@@ -1163,7 +1176,10 @@ PT_API int PTGroupSetScene(PTGroup* g, const PTSceneDesc* scene)
     return for_each_device(g, [&](int i) { return i == 0 ? PT_OK : set_scene(g->ctx[i], scene, false); });
 }
 
-PT_API int PTGroupRenderPass(PTGroup* g, const PTFrameParams* hostParams)
+PT_API int PTGroupRenderPassBatch(PTGroup* g, const PTFrameParams* hostParams, int count);
+PT_API int PTGroupRenderPass(PTGroup* g, const PTFrameParams* hostParams) { return PTGroupRenderPassBatch(g, hostParams, 1); }
+
+PT_API int PTGroupRenderPassBatch(PTGroup* g, const PTFrameParams* hostParams, int count)
 {
     if (!g) return fail(PT_ERR_INVALID_ARG, "group == NULL");
     PTFrameParams p;
@@ -1174,7 +1190,7 @@ PT_API int PTGroupRenderPass(PTGroup* g, const PTFrameParams* hostParams)
     const int world = (int)g->ctx.size();
     rc = for_each_device(g, [&](int i) -> int {
         PTContext* c = g->ctx[i];
-        int r = PTRenderPass(c, &p);                                   // owned tiles into the device's own ping-pong frames
+        int r = count == 1 ? PTRenderPass(c, hostParams) : PTRenderPassBatch(c, hostParams, count);   // owned tiles into the device's own ping-pong frames
         if (r) return r;
         // staged[i] (and packed[0], which the root unpacks in place) may only be overwritten once the root has scattered the
         // previous pass's tiles out of it: a straggling root must not see tiles of pass k+1 in the assembled frame of pass k

@@ -154,6 +154,20 @@ class PathTracerGroup:
             plugin.check(self.lib.PTGroupFlipFrames(self.group))
         return p
 
+    def OnRenderBatch(self, seeds):
+        """len(seeds) (1..8) consecutive passes as ONE launch sequence per device and one assembly (PTGroupRenderPassBatch)."""
+        ps = []
+        for k, seed in enumerate(seeds):
+            ps.append(self._scenes.frame_params(self.scene, self.width, self.height, spp=self.samplesPerPass,
+                                                current_sample=self._currentSample + k * max(1, self.samplesPerPass), seed=seed,
+                                                max_bounces=self.maxRayBounces))
+        arr = (abi.PTFrameParams * len(ps))(*ps)
+        plugin.check(self.lib.PTGroupRenderPassBatch(self.group, arr, len(ps)))
+        self._currentSample += len(ps) * max(1, self.samplesPerPass)
+        if self._currentSample < self.maxSamples:
+            plugin.check(self.lib.PTGroupFlipFrames(self.group))
+        return ps
+
     def Reset(self):
         self._currentSample = 0
         plugin.check(self.lib.PTGroupResetFrames(self.group))

@@ -61,6 +61,8 @@ def load_library():
         "PTFlipFrames": (i32, [vp]), "PTResetFrames": (i32, [vp]),
         "PTRenderPassTo": (i32, [vp, C.POINTER(abi.PTFrameParams), vp, vp]),
         "PTRenderPassBatchTo": (i32, [vp, C.POINTER(abi.PTFrameParams), i32, vp, vp]),
+        "PTRenderPassBatch": (i32, [vp, C.POINTER(abi.PTFrameParams), i32]),
+        "PTGroupRenderPassBatch": (i32, [vp, C.POINTER(abi.PTFrameParams), i32]),
         "PTSynchronize": (i32, [vp]), "PTReadback": (i32, [vp, vp, C.c_uint64]),
         "PTGetFramePointer": (vp, [vp, i32]), "PTGetStream": (vp, [vp]),
         "PTSetStatsLevel": (i32, [vp, i32]), "PTGetStats": (i32, [vp, C.POINTER(abi.PTStats)]), "PTResetStats": (i32, [vp]),
@@ -94,7 +96,7 @@ EXPORTED_SYMBOLS = [
     "PTBuildBVHDevice", "PTGetBVHBuildError", "PTGetBVHBuildMs",
     "BuildTLAS", "DestroyTLAS", "IsTLASReady", "GetTLASNodesSize", "GetTLASData",
     "PTCreate", "PTDestroy", "PTSetScene", "PTSetTileOwnership", "PTRenderPass", "PTFlipFrames", "PTResetFrames",
-    "PTRenderPassTo", "PTRenderPassBatchTo", "PTSynchronize", "PTReadback", "PTGetFramePointer", "PTGetStream", "PTSetStatsLevel", "PTGetStats",
+    "PTRenderPassTo", "PTRenderPassBatchTo", "PTRenderPassBatch", "PTGroupRenderPassBatch", "PTSynchronize", "PTReadback", "PTGetFramePointer", "PTGetStream", "PTSetStatsLevel", "PTGetStats",
     "PTResetStats", "PTSetProfiling", "PTGetTimings", "PTResetTimings", "PTProcessMeshes", "PTCopyTextureData", "PTPresent", "PTPresentToHost", "PTSetSchedule", "PTGetSchedule", "PTSetWavefrontIterations", "PTSetPassesInFlight", "PTGetPassesInFlight", "PTSetSubFrames",
     "PTGetOwnedTileSlots", "PTPackOwnedTiles", "PTUnpackTiles", "PTCreateMulti", "PTGroupDestroy", "PTGroupSize", "PTGroupGetContext",
     "PTGroupSetScene", "PTGroupRenderPass", "PTGroupFlipFrames", "PTGroupResetFrames", "PTGroupSynchronize", "PTGroupReadback",
