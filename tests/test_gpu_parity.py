@@ -560,6 +560,23 @@ def test_api_error_behaviour():
     assert lib.PTRenderPassTo(pt.ctx, C.byref(p), None, None) == abi.PT_ERR_INVALID_ARG
     assert lib.PTSetSchedule(pt.ctx, 9) == abi.PT_ERR_UNSUPPORTED and lib.PTSetSchedule(pt.ctx, -1) == abi.PT_OK
     assert lib.PTSetTileOwnership(pt.ctx, 3, 2) == abi.PT_ERR_INVALID_ARG
+    # round 3: scheduling knobs and pass batches
+    assert lib.PTSetPassesInFlight(pt.ctx, 99) == abi.PT_ERR_INVALID_ARG and lib.PTSetPassesInFlight(pt.ctx, -1) == abi.PT_ERR_INVALID_ARG
+    assert lib.PTSetPassesInFlight(pt.ctx, 2) == abi.PT_OK and lib.PTGetPassesInFlight(pt.ctx) == 2
+    assert lib.PTSetPassesInFlight(pt.ctx, 0) == abi.PT_OK and lib.PTGetPassesInFlight(pt.ctx) in (3, 6, 12)     # sized to GPU_MAX_HW_QUEUES
+    assert lib.PTSetSubFrames(pt.ctx, 0) == abi.PT_ERR_INVALID_ARG and lib.PTSetSubFrames(pt.ctx, 99) == abi.PT_ERR_INVALID_ARG
+    assert lib.PTSetSubFrames(pt.ctx, 1) == abi.PT_OK
+    assert lib.PTRenderPass(pt.ctx, C.byref(p)) == abi.PT_OK              # allocates the internal frame pair
+    frame = C.c_void_p(pt.lib.PTGetFramePointer(pt.ctx, 0))
+    two = (abi.PTFrameParams * 2)(p, scenes.frame_params(s, 64, 64, current_sample=1, seed=7))
+    assert lib.PTRenderPassBatchTo(pt.ctx, two, 0, frame, None) == abi.PT_ERR_INVALID_ARG
+    assert lib.PTRenderPassBatchTo(pt.ctx, two, 9, frame, None) == abi.PT_ERR_INVALID_ARG
+    assert lib.PTRenderPassBatchTo(pt.ctx, None, 2, frame, None) == abi.PT_ERR_INVALID_ARG
+    assert lib.PTRenderPassBatchTo(pt.ctx, two, 2, None, None) == abi.PT_ERR_INVALID_ARG
+    differ = (abi.PTFrameParams * 2)(p, scenes.frame_params(s, 64, 64, current_sample=1, seed=7, max_bounces=2))
+    assert lib.PTRenderPassBatchTo(pt.ctx, differ, 2, frame, None) == abi.PT_ERR_INVALID_ARG and b"RngSeedRoot" in lib.PTGetLastError()
+    assert lib.PTRenderPassBatchTo(pt.ctx, two, 2, frame, None) == abi.PT_OK and lib.PTSynchronize(pt.ctx) == abi.PT_OK
+    assert lib.PTRenderPassBatch(pt.ctx, two, 2) == abi.PT_OK and lib.PTSynchronize(pt.ctx) == abi.PT_OK
     # "Versioning": a host that does not set structSize is refused, one built against an older (shorter) header is served
     unsized = pt._bvhScene.desc()
     unsized.structSize = 0

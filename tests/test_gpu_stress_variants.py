@@ -81,6 +81,13 @@ def test_lds_regrouped_shade_kernel_is_bit_exact(tmp_path):
         out = str(tmp_path / f"sorted{v}.npz")
         subprocess.check_call([sys.executable, "-c", SORTED_CHILD, ROOT, out], env=dict(os.environ, PT_WF_SHADE_SORTED=v), timeout=600)
         outs[v] = np.load(out)
+    # the tail cut (off by default): once fewer than 4096 slots are alive the remaining launches return at once and the cleanup
+    # kernel finishes the stragglers -- same frames, same counters
+    out = str(tmp_path / "tailcut.npz")
+    subprocess.check_call([sys.executable, "-c", SORTED_CHILD, ROOT, out], env=dict(os.environ, PT_WF_TAIL_CUT="4096"), timeout=600)
+    tc = np.load(out)
+    for key in outs["0"].files:
+        assert np.array_equal(outs["0"][key].view(np.uint8), tc[key].view(np.uint8)), ("tail cut", key)
     for v in ("1", "2"):                                       # 1: regrouped through LDS, 2: pre / hit / post launches over compacted records
         for key in outs["0"].files:
             assert np.array_equal(outs["0"][key].view(np.uint8), outs[v][key].view(np.uint8)), (v, key)
