@@ -1,4 +1,4 @@
-import sys, time; sys.path.insert(0, '.')
+import os, sys, time; sys.path.insert(0, '.')
 from unity_webgpu_pathtracer_amd import scenes
 from unity_webgpu_pathtracer_amd.pathtracer import PathTracer
 W,H=1920,1080
@@ -8,6 +8,7 @@ for name in which:
     if name == "baked": s = scenes.bake_instances(s)
     for sched in (1,):
         pt = PathTracer(s, width=W, height=H, samplesPerPass=8, schedule=sched)
+        if os.environ.get("PT_SETS"): pt.set_passes_in_flight(int(os.environ["PT_SETS"]))
         for k in range(3): pt.OnRenderImage(100+k)
         pt.synchronize(); pt.reset_stats()
         t0=time.perf_counter()

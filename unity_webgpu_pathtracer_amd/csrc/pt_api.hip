@@ -84,7 +84,7 @@ struct RoctxRange {
 struct PTContext {
     int device = 0;
     hipStream_t stream = nullptr;
-    DeviceBuffer nodes, tris, attrs, materials, lights, lightConst, tex, tlas, instances, instByLeaf, envTex, envCdf;
+    DeviceBuffer nodes, tris, attrs, materials, lights, lightConst, tex, tlas, tlasBfs, instances, instByLeaf, envTex, envCdf;
     void* batchScratch = nullptr;               // PTRenderPassBatchTo under the megakernel: the frame the odd passes of a batch write
     size_t batchScratchBytes = 0;
     void* present = nullptr;                    // PTPresentToHost staging frame
@@ -173,7 +173,7 @@ int ensure_wavefront(PTContext* c, PTContext::WfSet& set, uint32_t numSlots, uin
     const uint32_t residentWaves = c->residentWaves;
     // the HAS_TLAS refill kernel always uses PT_WF_RANGE = 128 slots per wave; the plain one 64 or 128 (pt_wf_wide_ranges)
     const size_t traceWaves = pt_wf_max_trace_waves(numSlots, residentWaves);
-    const size_t spillBytes = traceWaves * 64u * (size_t)(PT_BVH_STACK_SIZE - PT_WF_LDS_STACK) * sizeof(uint2);
+    const size_t spillBytes = traceWaves * 64u * (size_t)(needTlas ? PT_WF_SPILL_ROW_ENTRIES : PT_BVH_STACK_SIZE - PT_WF_LDS_STACK) * sizeof(uint2);
     const size_t suspBytes = traceWaves * (size_t)(PT_WF_SUSPEND ? PT_WF_SUSPEND : 1u) * 6 * sizeof(uint4);
     const size_t tlasSpillBytes = needTlas ? traceWaves * 64u * (size_t)PT_BVH_STACK_SIZE * sizeof(uint32_t) : 0;
     size_t total = align(n * 4) * 2 + align(n * 16) * PT_F4_COUNT + align(n * 2) + align((size_t)maxIterations * 4 * PT_WF_ALIVE_SHARDS) +
@@ -524,7 +524,7 @@ PT_API int PTDestroy(PTContext* c)
     if (!c) return PT_OK;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
-    for (auto* b : {&c->nodes, &c->tris, &c->attrs, &c->materials, &c->lights, &c->lightConst, &c->tex, &c->tlas, &c->instances, &c->instByLeaf, &c->envTex, &c->envCdf}) if (b->ptr) hipFree(b->ptr);
+    for (auto* b : {&c->nodes, &c->tris, &c->attrs, &c->materials, &c->lights, &c->lightConst, &c->tex, &c->tlas, &c->tlasBfs, &c->instances, &c->instByLeaf, &c->envTex, &c->envCdf}) if (b->ptr) hipFree(b->ptr);
     for (int i = 0; i < 2; i++) if (c->frames[i]) hipFree(c->frames[i]);
     if (c->dStats) hipFree(c->dStats);
     if (c->present) hipFree(c->present);
@@ -588,7 +588,7 @@ int set_scene(PTContext* c, const PTSceneDesc* hostScene, bool validate)
     if (textures && (rc = upload(c, c->tex, s->textureData, (size_t)s->textureDataUints * 4))) return rc;
     if (tlasOn && (rc = upload(c, c->tlas, s->tlasData, (size_t)s->tlasDataFloats * 4))) return rc;
     if (tlasOn && (rc = upload(c, c->instances, s->gpuInstances, (size_t)s->instanceCount * 144))) return rc;
-    std::vector<float> byLeaf;
+    std::vector<float> byLeaf, bfs;
     if (tlasOn) {
         // what entering an instance reads (util/tlas.hlsl:129-147: TLASData[TLASIndexOffset + k] -> GPUInstance) as ONE record per
         // index slot k, in the order the TLAS leaves list them: the kernels save a dependent fetch per instance entry
@@ -602,6 +602,25 @@ int set_scene(PTContext* c, const PTSceneDesc* hostScene, bool validate)
             memcpy(&byLeaf[k * 24 + 20], &idx, 4);
         }
         if ((rc = upload(c, c->instByLeaf, byLeaf.data(), byLeaf.size() * sizeof(float)))) return rc;
+        // the nodes reachable from node 0, renumbered breadth-first: the top of the tree -- what nearly every ray visits -- becomes
+        // the FIRST nodes of the array, which pt_wf_trace_refill_tlas copies into LDS.  Children indices are rewritten, every other
+        // word (boxes, instance count, first index slot) is copied, so a walk visits the same nodes in the same order.
+        const uint32_t tlasNodes = s->tlasIndexOffset / 16u;
+        std::vector<uint32_t> order(1, 0u), renum(tlasNodes, 0xFFFFFFFFu);
+        renum[0] = 0u;
+        for (size_t i = 0; i < order.size(); ++i) {
+            const uint32_t* n = T + (size_t)order[i] * 16;
+            if (n[11] != 0u) continue;                                       // a leaf: instance count > 0
+            for (uint32_t child : {n[3], n[7]})                              // < tlasNodes when the scene was validated; otherwise left alone
+                if (child < tlasNodes && renum[child] == 0xFFFFFFFFu) { renum[child] = (uint32_t)order.size(); order.push_back(child); }
+        }
+        bfs.resize(order.size() * 16);
+        for (size_t i = 0; i < order.size(); ++i) {
+            uint32_t* d = (uint32_t*)&bfs[i * 16];
+            memcpy(d, T + (size_t)order[i] * 16, 64);
+            if (d[11] == 0u) { if (d[3] < tlasNodes) d[3] = renum[d[3]]; if (d[7] < tlasNodes) d[7] = renum[d[7]]; }
+        }
+        if ((rc = upload(c, c->tlasBfs, bfs.data(), bfs.size() * sizeof(float)))) return rc;
     }
     std::vector<float> cdf;
     float cdfSum = 0.0f;
@@ -638,6 +657,8 @@ int set_scene(PTContext* c, const PTSceneDesc* hostScene, bool validate)
     c->scene.tlas = tlasOn ? (const float*)c->tlas.ptr : nullptr;
     c->scene.instances = tlasOn ? (const float4*)c->instances.ptr : nullptr;
     c->scene.instByLeaf = tlasOn ? (const float4*)c->instByLeaf.ptr : nullptr;
+    c->scene.tlasBfs = tlasOn ? (const float*)c->tlasBfs.ptr : nullptr;
+    c->scene.tlasNodeCount = tlasOn ? (uint32_t)(bfs.size() / 16) : 0u;
     c->scene.tlasIndexOffset = tlasOn ? s->tlasIndexOffset : 0u;
     c->scene.hasTlas = tlasOn ? 1u : 0u;
     c->scene.envTex = envOn ? (const float4*)c->envTex.ptr : nullptr;

@@ -93,6 +93,9 @@ struct DScene {
     const float4* instances;
     const float4* instByLeaf;   // derived by PTSetScene: entry k = worldToLocal (4 rows), offsets row, {instance index} of the instance that TLAS index slot k
                                 // names -- 6 float4, in the order TLAS leaves list them: entering an instance is ONE fetch, not index -> record
+    const float*  tlasBfs;      // derived by PTSetScene: the TLAS nodes reachable from node 0, renumbered breadth-first (children indices
+                                // rewritten, everything else copied): the refill kernel keeps the first nodes of THIS array in LDS
+    uint32_t tlasNodeCount;     // nodes in tlasBfs
     uint32_t tlasIndexOffset;
     uint32_t hasTlas;
     // HAS_ENVIRONMENT_TEXTURE (util/sky.hlsl:7-88): RGBAFloat texels, running sum of their grayscale, its last value

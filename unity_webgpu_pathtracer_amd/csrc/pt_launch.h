@@ -71,6 +71,26 @@ enum : uint32_t { PT_F4_RAY0 = 0, PT_F4_RAY1 = 2, PT_F4_RAY2 = 4, PT_F4_RAD = 6,
 #ifndef PT_WF_LDS_STACK
 #define PT_WF_LDS_STACK 8       // traversal-stack entries per lane kept in LDS by the refill / persistent trace kernels; deeper ones go to stackSpill
 #endif
+// HAS_TLAS refill kernel (pt_wf_trace_refill_tlas): waves per workgroup sharing one LDS copy of the top of the TLAS (1 = one-wave
+// workgroups, nodes from memory), nodes in that copy (64 bytes each), CWBVH stack entries per lane kept in LDS by that variant.
+// 8 waves x (4 x 512 B CWBVH stack + 8 x 128 B TLAS stack + 256 B exchange) + 400 x 64 B = 52.2 KB: three workgroups = 24 waves per CU.
+// Measured (200-instance scene, 1080p / 8 spp, round 3): 1 wave 2,327 Mrays/s, 8 waves with all 399 nodes in LDS 2,155, 8 waves with
+// one node in LDS 2,043 -- the copy is worth 6 %, the eight-wave workgroup costs 12 %: the TLAS walk is not bound by where its nodes
+// come from.  Default 1; the stress build (csrc/Makefile) runs the 8-wave variant through the parity suite.
+#ifndef PT_WF_TLAS_WG_WAVES
+#define PT_WF_TLAS_WG_WAVES 1u
+#endif
+#ifndef PT_WF_TLAS_CACHE_NODES
+#define PT_WF_TLAS_CACHE_NODES 400u
+#endif
+#ifndef PT_WF_TLAS_CHUNK
+#define PT_WF_TLAS_CHUNK 64u     // slots per chunk the waves of such a workgroup take from their shared range (power of two <= 64 x ... <= PT_WF_RANGE)
+#endif
+#ifndef PT_WF_TLAS_BLAS_LDS_STACK
+#define PT_WF_TLAS_BLAS_LDS_STACK (PT_WF_LDS_STACK < 4 ? PT_WF_LDS_STACK : 4)
+#endif
+// entries per slab row: the deepest overflow any trace kernel of the build can have
+#define PT_WF_SPILL_ROW_ENTRIES (PT_BVH_STACK_SIZE - (PT_WF_TLAS_BLAS_LDS_STACK < PT_WF_LDS_STACK ? PT_WF_TLAS_BLAS_LDS_STACK : PT_WF_LDS_STACK))
 struct PTWfBuffers {
     uint32_t* flags;            // [numSlots] packed state word
     uint32_t* rng;              // [numSlots]

@@ -20,6 +20,7 @@
 // same per-path order as in schedule 0, so frames and counters are bit-identical between schedules and to the oracle.
 #include "pt_device.h"
 #include "pt_launch.h"
+#include <type_traits>
 
 namespace {
 
@@ -219,6 +220,11 @@ static_assert(PT_WF_RANGE >= 64u && (PT_WF_RANGE & (PT_WF_RANGE - 1u)) == 0u,
 #define PT_WF_STEP ray_step
 #endif
 
+// LDS words the lanes of a wave exchange through, as LDS-address-space pointers: through a generic `volatile uint32_t*` every
+// access is a FLAT instruction (the compiler does not infer the address space of a volatile access) -- it travels the
+// texture-address path and counts against both memory counters.
+typedef volatile __attribute__((address_space(3))) uint32_t* pt_lds_u32;
+typedef volatile __attribute__((address_space(3))) uint16_t* pt_lds_u16;
 // number of set bits of a wave mask below this lane (v_mbcnt: no per-lane 64-bit "lanes below me" mask to keep in registers)
 PT_DEV uint32_t rank_below(unsigned long long m)
 {
@@ -292,7 +298,7 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(
     const uint32_t gw = blockIdx.x;
     const uint32_t numWaves = (B.numSlots + RANGE - 1u) / RANGE;
     const uint32_t slotBase = gw * RANGE;
-    volatile uint32_t* xchg = s_xchg;
+    pt_lds_u32 xchg = (pt_lds_u32)&s_xchg[0];
     if (lane == 0u) s_gw = gw;
 
     // candidates: the main launch scans the flag words of its slot range, kind-major; the tail launch walks the records that
@@ -545,57 +551,101 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(
 #ifndef PT_WF_TLAS_MIN_WAVES
 #define PT_WF_TLAS_MIN_WAVES 6      // 80 VGPRs, no scratch (without the SLP vectorizer); 5 waves: -3 %
 #endif
-template <bool STATS>
-__global__ __launch_bounds__(64, PT_WF_TLAS_MIN_WAVES) void pt_wf_trace_refill_tlas(DScene S, PTWfBuffers B, uint32_t iteration)
+// WAVES = 1: one-wave workgroups, TLAS nodes fetched from HBM / L2 (round 2).
+// WAVES > 1 (round 3, the default for TLAS trees below 65,536 nodes): the WAVES waves of a workgroup share ONE copy of the top of
+// the TLAS in LDS -- the first PT_WF_TLAS_CACHE_NODES nodes of S.tlasBfs, the breadth-first renumbering PTSetScene makes of the
+// reference's node array (same nodes, same children, same visiting order: only the indices differ, and nothing observable
+// depends on them).  The TLAS walk is a chain of ~13 dependent 64-byte fetches per ray at a quarter of the lanes (57 % of this
+// kernel's time when they come from memory); from LDS a step costs a ds_read_b128 x 4 instead of a vector-memory round trip
+// and takes 52 of the ray's ~145 sixteen-byte lane requests off the texture-address path.  To pay for the 25.6 KB copy at the same
+// 24 waves per CU the per-wave LDS shrinks: PT_WF_TLAS_BLAS_LDS_STACK (4) CWBVH stack entries (deeper ones in the HBM slab, as
+// before) and 16-bit TLAS stack entries.  Each wave still owns its own slot range and never waits for another after the
+// one barrier that follows the copy.
+template <bool STATS, uint32_t WAVES>
+__global__ __launch_bounds__(64 * WAVES, PT_WF_TLAS_MIN_WAVES) void pt_wf_trace_refill_tlas(DScene S, PTWfBuffers B, uint32_t iteration)
 {
-    __shared__ uint2 s_stack[PT_WF_LDS_STACK][64];
+    constexpr bool kCached = WAVES > 1u;
+    constexpr uint32_t kBlasLds = kCached ? (uint32_t)PT_WF_TLAS_BLAS_LDS_STACK : (uint32_t)PT_WF_LDS_STACK;
+    typedef typename std::conditional<kCached, uint16_t, uint32_t>::type tentry_t;
+    __shared__ uint2 s_stack[WAVES][kBlasLds][64];
     if (tail_cut(B, iteration)) return;
-    __shared__ uint32_t s_tstack[PT_WF_TLAS_LDS_STACK][64];
-    __shared__ uint32_t s_xchg[64];
-    __shared__ uint32_t s_gw;
-    const uint32_t lane = threadIdx.x;
-    const uint32_t gw = blockIdx.x;
-    const uint32_t slotBase = gw * PT_WF_RANGE;
-    volatile uint32_t* xchg = s_xchg;
-    volatile uint32_t* tlds = &s_tstack[0][lane];
-    if (lane == 0u) s_gw = gw;
-    const uint32_t nItems = 3u * PT_WF_RANGE;
-    const float* T = S.tlas;
+    __shared__ tentry_t s_tstack[WAVES][PT_WF_TLAS_LDS_STACK][64];
+    __shared__ uint32_t s_xchg[WAVES][64];
+    __shared__ uint32_t s_gw[WAVES];
+    __shared__ float4 s_tcache[kCached ? PT_WF_TLAS_CACHE_NODES * 4u : 1u];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = kCached ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0u;     // wave-uniform: LDS bases stay scalar
+    const uint32_t gw = blockIdx.x * WAVES + wv;
+    // WAVES = 1: the wave scans its own PT_WF_RANGE slots.  WAVES > 1: the workgroup's waves SHARE its WAVES x PT_WF_RANGE slots, in
+    // chunks of PT_WF_TLAS_CHUNK slots handed out by an LDS counter -- a wave whose chunk is scanned takes the next one while its
+    // rays are still in flight, so the waves of a workgroup run out of work together (with a fixed range per wave the workgroup
+    // held its LDS and wave slots until its SLOWEST range was done: measured 2.9x slower, 8 waves without the LDS copy).
+    constexpr uint32_t kChunk = kCached ? PT_WF_TLAS_CHUNK : PT_WF_RANGE;
+    __shared__ uint32_t s_next;
+    const uint32_t wgBase = blockIdx.x * WAVES * PT_WF_RANGE;
+    uint32_t slotBase = gw * PT_WF_RANGE;
+    pt_lds_u32 xchg = (pt_lds_u32)&s_xchg[wv][0];
+    typedef typename std::conditional<kCached, pt_lds_u16, pt_lds_u32>::type tlds_t;
+    tlds_t tlds = (tlds_t)&s_tstack[wv][0][lane];
+    if (lane == 0u) s_gw[wv] = gw;
+    const uint32_t nItems = 3u * kChunk;
+    const float* T = S.tlasBfs;
+    uint32_t cachedNodes = 0u;
+    if (kCached) {
+        cachedNodes = S.tlasNodeCount < PT_WF_TLAS_CACHE_NODES ? S.tlasNodeCount : PT_WF_TLAS_CACHE_NODES;
+        for (uint32_t i = threadIdx.x; i < cachedNodes * 4u; i += 64u * WAVES) s_tcache[i] = ((const float4*)T)[i];
+        if (threadIdx.x == 0u) s_next = 0u;
+        __syncthreads();
+    }
 
     Counters cn = {};
-    TravStackT<PT_WF_LDS_STACK, true> st;
-    st.lds = &s_stack[0][lane];
+    TravStackT<kBlasLds, true> st;
+    st.lds = &s_stack[wv][0][lane];
     st.stride = 64u;
     st.gbase = B.stackSpill;
-    st.gwave = PT_LDS_WORD(s_gw);
+    st.gwave = PT_LDS_WORD(s_gw[wv]);
     RayState rs;
     rs.sp = 0u; rs.anyHit = false; rs.overflow = false;
     bool have = false, inBlas = false, needPop = false, hitFound = false;
-    uint32_t mySlot = 0u, myKind = 0u, cursor = 0u;
+    uint32_t mySlot = 0u, myKind = 0u, cursor = kCached ? nItems : 0u;       // WAVES > 1: no chunk yet
+    bool more = kCached;                                                      // chunks may remain (WAVES > 1)
     v3 O = mk3(0.0f), rD = mk3(0.0f);
     uint32_t nodeIndex = 0u, tsp = 0u, nextInst = 0u, instLeft = 0u;
     uint32_t nodeOffset = 0u, triOffset = 0u, attrOffset = 0u, instIndex = 0u;
 
+    // The empty asm statements keep the LDS access and the HBM-slab access of an entry in their own branches.  Without them the
+    // compiler sinks the two into ONE access through a selected pointer -- a FLAT load / store (round 2's kernel had two of each in
+    // its walk loop): a flat access counts against both the vector-memory and the LDS counter, and one that resolves to LDS
+    // still travels the texture-address path.
     auto tpush = [&](uint32_t v) {
-        if (tsp < PT_WF_TLAS_LDS_STACK) tlds[tsp * 64u] = v;
-        else if (tsp < PT_BVH_STACK_SIZE) B.tlasSpill[spill_row(PT_LDS_WORD(s_gw)) * PT_BVH_STACK_SIZE + tsp] = v;
+        if (tsp < PT_WF_TLAS_LDS_STACK) { tlds[tsp * 64u] = (tentry_t)v; asm volatile("" ::: "memory"); }
+        else if (tsp < PT_BVH_STACK_SIZE) B.tlasSpill[spill_row(PT_LDS_WORD(s_gw[wv])) * PT_BVH_STACK_SIZE + tsp] = v;
         tsp++;
     };
     auto tpop = [&]() -> uint32_t {
         --tsp;
-        if (tsp < PT_WF_TLAS_LDS_STACK) return tlds[tsp * 64u];
-        if (tsp < PT_BVH_STACK_SIZE) return B.tlasSpill[spill_row(PT_LDS_WORD(s_gw)) * PT_BVH_STACK_SIZE + tsp];
+        if (tsp < PT_WF_TLAS_LDS_STACK) { uint32_t v = tlds[tsp * 64u]; asm volatile("" : "+v"(v)); return v; }
+        if (tsp < PT_BVH_STACK_SIZE) return B.tlasSpill[spill_row(PT_LDS_WORD(s_gw[wv])) * PT_BVH_STACK_SIZE + tsp];
         return 0u;
     };
 
     while (true) {
         uint32_t nIdle = (uint32_t)__popcll(__ballot(!have));
-        while (cursor < nItems && (nIdle >= PT_WF_REFILL || nIdle == 64u)) {
+        while ((kCached || cursor < nItems) && (nIdle >= PT_WF_REFILL || nIdle == 64u)) {
+            if (kCached && cursor >= nItems) {
+                if (!more) break;
+                uint32_t c = 0u;
+                if (lane == 0u) c = atomicAdd(&s_next, 1u);
+                c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+                if (c >= WAVES * PT_WF_RANGE / kChunk || wgBase + c * kChunk >= B.numSlots) { more = false; break; }
+                slotBase = wgBase + c * kChunk;
+                cursor = 0u;
+            }
             const unsigned long long idle = __ballot(!have);
             const uint32_t rankI = rank_below(idle);
             const uint32_t item = cursor + lane;
-            const uint32_t kind = item / PT_WF_RANGE;
-            const uint32_t slot = slotBase + (item & (PT_WF_RANGE - 1u));
+            const uint32_t kind = item / kChunk;
+            const uint32_t slot = slotBase + (item & (kChunk - 1u));
             bool valid = item < nItems && slot < B.numSlots;
             if (valid) valid = ray_exists(B.flags[slot], kind);
             const unsigned long long V = __ballot(valid);
@@ -608,8 +658,8 @@ __global__ __launch_bounds__(64, PT_WF_TLAS_MIN_WAVES) void pt_wf_trace_refill_t
             __builtin_amdgcn_wave_barrier();
             if (!have && rankI < take) {
                 const uint32_t it = xchg[rankI];
-                myKind = it / PT_WF_RANGE;
-                mySlot = slotBase + (it & (PT_WF_RANGE - 1u));
+                myKind = it / kChunk;
+                mySlot = slotBase + (it & (kChunk - 1u));
                 v3 d;
                 fetch_ray(B, mySlot, myKind, O, d);
                 if (myKind == 0u) cn.closestRays++; else cn.shadowRays++;
@@ -630,7 +680,7 @@ __global__ __launch_bounds__(64, PT_WF_TLAS_MIN_WAVES) void pt_wf_trace_refill_t
             nIdle = (uint32_t)__popcll(__ballot(!have));
         }
         if (nIdle == 64u) break;
-        const uint32_t stopAt = cursor < nItems ? PT_WF_REFILL : 64u;
+        const uint32_t stopAt = (kCached ? more : cursor < nItems) ? PT_WF_REFILL : 64u;
         do {
 #ifdef PT_TLAS_DIAG
             // diagnostics builds (tools/experiments/tlas_diag.sh): wave-level event counts / clock ticks through the two pixel counters
@@ -647,7 +697,12 @@ __global__ __launch_bounds__(64, PT_WF_TLAS_MIN_WAVES) void pt_wf_trace_refill_t
             //      of two, instByLeaf: no change) nor its scheduling (one TLAS step per wave iteration, a quorum for entering the block,
             //      triangle parking: all slower) is the lever; letting the last few walkers wait for company (PT_WF_TLAS_CONT) is
             //      worth 3 %.  What is left is the work itself: 19 TLAS steps per ray at a quarter of the lanes.
-            const bool walkT = have && !inBlas;
+#ifndef PT_WF_TLAS_SPLIT_ENTRY
+#define PT_WF_TLAS_SPLIT_ENTRY 1     // 1: the walk loop only visits TLAS nodes; lanes that reached a leaf (or still have instances of their leaf left) enter
+                                     // their instance together in ONE block after it.  0 (round 2): the ~130-instruction entry path sits inside the walk loop and runs
+                                     // in most of its ~11 steps per execution for one or two lanes each
+#endif
+            const bool walkT = have && !inBlas && (!PT_WF_TLAS_SPLIT_ENTRY || instLeft == 0u);
 #if PT_WF_TLAS_QUORUM > 0
             const uint32_t nWalk = (uint32_t)__popcll(__ballot(walkT)), nIn = (uint32_t)__popcll(__ballot(have && inBlas));
             const bool runWalk = nWalk >= PT_WF_TLAS_QUORUM || nIn == 0u;
@@ -658,6 +713,25 @@ __global__ __launch_bounds__(64, PT_WF_TLAS_MIN_WAVES) void pt_wf_trace_refill_t
             if (PT_TLAS_DIAG == 1 && dl0 && __ballot(walkT && runWalk) != 0ull) cn.pixelsRead++;      // executions of the TLAS-walk block
             if (PT_TLAS_DIAG == 3 && walkT) cn.pixelsRead++;                                        // lanes entering the walk block
 #endif
+            // enter the next instance of the current TLAS leaf (tlas.hlsl:129-147)
+            // ONE fetch: the record PTSetScene laid out per TLAS index slot (worldToLocal, offsets, instance index) instead of
+            // TLASData[TLASIndexOffset + k] -> instance record (two dependent fetches; same values)
+            auto enter_instance = [&]() {
+                const float4* ip = S.instByLeaf + (size_t)nextInst * 6;
+                const float4 w0 = ip[0], w1 = ip[1], w2 = ip[2], w3 = ip[3], ints = ip[4];
+                instIndex = pt_asuint(ip[5].x);
+                nextInst++; instLeft--;
+                if (STATS) cn.instanceVisits++;
+                nodeOffset = pt_asuint(ints.x); triOffset = pt_asuint(ints.y); attrOffset = pt_asuint(ints.z);
+                const v3 wd = xyz(f4_array(B, 2u * myKind)[2u * (size_t)mySlot + 1u]);           // the direction row of the lane's ray record
+                const v4 lo4 = mul44c(w0, w1, w2, w3, v4{O.x, O.y, O.z, 1.0f});
+                const v4 ld4 = mul44c(w0, w1, w2, w3, v4{wd.x, wd.y, wd.z, 0.0f});
+                const float tKeep = rs.hit.t;
+                ray_begin(rs, mk3(lo4.x, lo4.y, lo4.z), mk3(ld4.x, ld4.y, ld4.z), myKind != 0u);
+                rs.hit.t = tKeep;
+                hitFound = false;
+                inBlas = true;
+            };
             if (walkT && runWalk) {
                 bool finished = false;
                 for (uint32_t stepT = 0; stepT < PT_WF_TLAS_STEPS; ++stepT) {
@@ -667,34 +741,25 @@ __global__ __launch_bounds__(64, PT_WF_TLAS_MIN_WAVES) void pt_wf_trace_refill_t
 #ifdef PT_TLAS_DIAG
                     if (PT_TLAS_DIAG == 2) { cn.pixelsRead++; if (lane == (uint32_t)(__ffsll((long long)__ballot(true)) - 1)) cn.pixelsWritten++; }   // lane-steps / wave-steps inside the walk block
 #endif
-                    if (instLeft > 0u) {
-                        // enter the next instance of the current TLAS leaf (tlas.hlsl:129-147)
-                        // ONE fetch: the record PTSetScene laid out per TLAS index slot (worldToLocal, offsets, instance index) instead of
-                        // TLASData[TLASIndexOffset + k] -> instance record (two dependent fetches; same values)
-                        const float4* ip = S.instByLeaf + (size_t)nextInst * 6;
-                        const float4 w0 = ip[0], w1 = ip[1], w2 = ip[2], w3 = ip[3], ints = ip[4];
-                        instIndex = pt_asuint(ip[5].x);
-                        nextInst++; instLeft--;
-                        if (STATS) cn.instanceVisits++;
-                        nodeOffset = pt_asuint(ints.x); triOffset = pt_asuint(ints.y); attrOffset = pt_asuint(ints.z);
-                        const v3 wd = xyz(f4_array(B, 2u * myKind)[2u * (size_t)mySlot + 1u]);           // the direction row of the lane's ray record
-                        const v4 lo4 = mul44c(w0, w1, w2, w3, v4{O.x, O.y, O.z, 1.0f});
-                        const v4 ld4 = mul44c(w0, w1, w2, w3, v4{wd.x, wd.y, wd.z, 0.0f});
-                        const float tKeep = rs.hit.t;
-                        ray_begin(rs, mk3(lo4.x, lo4.y, lo4.z), mk3(ld4.x, ld4.y, ld4.z), myKind != 0u);
-                        rs.hit.t = tKeep;
-                        hitFound = false;
-                        inBlas = true;
-                        break;
-                    }
+                    if (!PT_WF_TLAS_SPLIT_ENTRY && instLeft > 0u) { enter_instance(); break; }
                     if (needPop) {
                         if (tsp == 0u) { finished = true; break; }
                         nodeIndex = tpop();
                         needPop = false;
                     }
                     // visit TLAS node nodeIndex (tlas.hlsl:246-331)
-                    const float4* np = (const float4*)(T + (size_t)nodeIndex * 16u);
-                    const float4 a = np[0], b = np[1], c = np[2], e = np[3];
+                    float4 a, b, c, e;
+                    if (kCached && nodeIndex < cachedNodes) {
+                        const float4* cp = &s_tcache[nodeIndex * 4u];
+                        a = cp[0]; b = cp[1]; c = cp[2]; e = cp[3];
+                        asm volatile("" : "+v"(a.x), "+v"(b.x), "+v"(c.x), "+v"(e.x));        // ds_read_b128 here, global_load below: never one flat load (see tpush)
+                    } else {
+                        const float4* np = (const float4*)(T + (size_t)nodeIndex * 16u);
+                        a = np[0]; b = np[1]; c = np[2]; e = np[3];
+                        // all four rows requested before the first use: left alone, the compiler fetches the instance count first, waits, and
+                        // requests the boxes (or the leaf's first index) under the branch on it -- two dependent round trips per TLAS step
+                        asm volatile("" : "+v"(a.x), "+v"(b.x), "+v"(c.x), "+v"(c.w), "+v"(e.x), "+v"(e.w));
+                    }
                     if (STATS) cn.tlasNodeVisits++;
                     const uint32_t instanceCount = pt_asuint(c.w);
                     if (instanceCount == 0u) {
@@ -720,6 +785,7 @@ __global__ __launch_bounds__(64, PT_WF_TLAS_MIN_WAVES) void pt_wf_trace_refill_t
                         nextInst = pt_asuint(e.w);
                         instLeft = instanceCount;
                         needPop = true;                                    // after the leaf's instances
+                        if (PT_WF_TLAS_SPLIT_ENTRY) break;                 // to the entry block below
                     }
                 }
                 if (finished) {
@@ -728,6 +794,7 @@ __global__ __launch_bounds__(64, PT_WF_TLAS_MIN_WAVES) void pt_wf_trace_refill_t
                     have = false;
                 }
             }
+            if (PT_WF_TLAS_SPLIT_ENTRY && have && !inBlas && instLeft > 0u) enter_instance();
 #ifdef PT_TLAS_DIAG
             const unsigned long long dT1 = __builtin_readcyclecounter();
             if (PT_TLAS_DIAG == 3 && have && inBlas) cn.pixelsWritten++;                             // lanes in the CWBVH step
@@ -784,7 +851,7 @@ __global__ __launch_bounds__(64, PT_WF_TLAS_MIN_WAVES) void pt_wf_trace_refill_t
         } while (nIdle < stopAt);
     }
     __builtin_amdgcn_wave_barrier();
-    flush_counters<STATS>(cn, B.statRows, (B.numSlots >> 6) + *PT_LDS_WORD(s_gw), lane);
+    flush_counters<STATS>(cn, B.statRows, (B.numSlots >> 6) + *PT_LDS_WORD(s_gw[wv]), lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -824,7 +891,7 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_persist
     const uint32_t numChunks = (B.numSlots + PT_WF_CHUNK - 1u) / PT_WF_CHUNK;
     const uint32_t shard = blockIdx.x & (PT_WF_SHARDS - 1u);
     const uint32_t nItems = 3u * PT_WF_CHUNK;
-    volatile uint32_t* xchg = s_xchg;
+    pt_lds_u32 xchg = (pt_lds_u32)&s_xchg[0];
 
     Counters cn = {};
     TravStackT<PT_WF_LDS_STACK, true> st;
@@ -1108,7 +1175,7 @@ __global__ __launch_bounds__(64, PT_WF_FUSED_WAVES) void pt_wf_fused(DScene S, P
     __shared__ uint32_t s_gw;
     const uint32_t lane = threadIdx.x;
     const uint32_t ctxBase = blockIdx.x * (K * 64u);                 // context = ctxBase + group * 64 + lane
-    volatile uint32_t* xchg = s_xchg;
+    pt_lds_u32 xchg = (pt_lds_u32)&s_xchg[0];
     volatile uint32_t* pix = &s_pix[0][0];
     volatile uint32_t* cnt = s_cnt;
 #pragma unroll
@@ -1943,8 +2010,14 @@ hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const PT
                 launches++;
             }
         } else if (tlas && tlasRefill) {
-            if (fullStats) hipLaunchKernelGGL(pt_wf_trace_refill_tlas<true>, dim3(refillBlocks), dim3(64), 0, stream, S, B, it);
-            else hipLaunchKernelGGL(pt_wf_trace_refill_tlas<false>, dim3(refillBlocks), dim3(64), 0, stream, S, B, it);
+            if (PT_WF_TLAS_WG_WAVES > 1u && S.tlasNodeCount <= 0xFFFFu) {     // 16-bit TLAS stack entries
+                const uint32_t wgs = (refillBlocks + PT_WF_TLAS_WG_WAVES - 1u) / PT_WF_TLAS_WG_WAVES;
+                if (fullStats) hipLaunchKernelGGL((pt_wf_trace_refill_tlas<true, PT_WF_TLAS_WG_WAVES>), dim3(wgs), dim3(64u * PT_WF_TLAS_WG_WAVES), 0, stream, S, B, it);
+                else hipLaunchKernelGGL((pt_wf_trace_refill_tlas<false, PT_WF_TLAS_WG_WAVES>), dim3(wgs), dim3(64u * PT_WF_TLAS_WG_WAVES), 0, stream, S, B, it);
+            } else {
+                if (fullStats) hipLaunchKernelGGL((pt_wf_trace_refill_tlas<true, 1u>), dim3(refillBlocks), dim3(64), 0, stream, S, B, it);
+                else hipLaunchKernelGGL((pt_wf_trace_refill_tlas<false, 1u>), dim3(refillBlocks), dim3(64), 0, stream, S, B, it);
+            }
         } else if (tlas) {
             if (fullStats) hipLaunchKernelGGL((pt_wf_trace<true, true>), dim3(nb * 3u), dim3(256), 0, stream, S, B, it);
             else hipLaunchKernelGGL((pt_wf_trace<false, true>), dim3(nb * 3u), dim3(256), 0, stream, S, B, it);
