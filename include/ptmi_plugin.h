@@ -97,7 +97,7 @@ typedef struct PTContext PTContext;   /* opaque; one per GPU (one process per GP
  * a scene that would make a kernel read out of bounds is refused with PT_ERR_INVALID_ARG instead of faulting the GPU. */
 typedef struct PTSceneDesc {
     uint32_t        structSize;      uint32_t _pad3;             /* = sizeof(PTSceneDesc) of the host's header */
-    const void*     bvhNodes;        uint64_t bvhNodesBytes;     /* PTCwbvhNode[]          "BVHNodes" */
+    const void*     bvhNodes;        uint64_t bvhNodesBytes;     /* PTCwbvhNode[]          "BVHNodes"; below 4 GiB (53 M nodes): the kernels address nodes with 32-bit byte offsets */
     const void*     bvhTris;         uint64_t bvhTrisBytes;      /* PTCwbvhTri[]           "BVHTris"  */
     const void*     triAttrs;        uint64_t triAttrsBytes;     /* PTTriangleAttributes[] "TriangleAttributesBuffer" */
     const void*     materials;       uint32_t materialCount;  uint32_t _pad0;  /* PTMaterialData[] "Materials" */

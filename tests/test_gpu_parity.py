@@ -547,6 +547,9 @@ def test_api_error_behaviour():
     d.bvhNodesBytes = 81                                           # not a multiple of the 80-byte node
     assert lib.PTSetScene(pt.ctx, C.byref(d)) == abi.PT_ERR_INVALID_ARG
     d = pt._bvhScene.desc()
+    d.bvhNodesBytes = 80 * ((1 << 32) // 80 + 1)                   # 4 GiB of nodes and more: refused before a byte is read (32-bit node offsets)
+    assert lib.PTSetScene(pt.ctx, C.byref(d)) == abi.PT_ERR_INVALID_ARG and b"4 GiB" in lib.PTGetLastError()
+    d = pt._bvhScene.desc()
     d.features |= abi.PT_FEATURE_HAS_ENVIRONMENT_TEXTURE
     assert lib.PTSetScene(pt.ctx, C.byref(d)) == abi.PT_ERR_INVALID_ARG
     zero = scenes.frame_params(s, 64, 64)

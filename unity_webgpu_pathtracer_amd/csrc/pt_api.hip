@@ -562,6 +562,7 @@ int set_scene(PTContext* c, const PTSceneDesc* hostScene, bool validate)
                    s->tlasIndexOffset >= s->tlasDataFloats || s->tlasIndexOffset % 16 != 0))
         return fail(PT_ERR_INVALID_ARG, "HAS_TLAS needs tlasData (nodes + indices), tlasIndexOffset and gpuInstances");
     if (!s->bvhNodes || s->bvhNodesBytes < 80 || s->bvhNodesBytes % 80) return fail(PT_ERR_INVALID_ARG, "bvhNodes must be a non-empty multiple of 80 bytes");
+    if ((uint64_t)s->bvhNodesBytes >= (1ull << 32)) return fail(PT_ERR_INVALID_ARG, "bvhNodes of 4 GiB and more are not supported (the kernels address nodes with 32-bit byte offsets)");
     if (!s->bvhTris || s->bvhTrisBytes % 48) return fail(PT_ERR_INVALID_ARG, "bvhTris must be a multiple of 48 bytes");
     if (!s->triAttrs || s->triAttrsBytes % 128) return fail(PT_ERR_INVALID_ARG, "triAttrs must be a multiple of 128 bytes");
     if (!s->materials || s->materialCount == 0) return fail(PT_ERR_INVALID_ARG, "materials missing");

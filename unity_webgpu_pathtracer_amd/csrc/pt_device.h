@@ -202,7 +202,11 @@ PT_DEV uint32_t cwbvh_node_hitmask(v3 origin, v3 invDir, uint32_t octinv4, float
         uint32_t loy = ny ? qhiy : qloy, hiy = ny ? qloy : qhiy;
         uint32_t loz = nz ? qhiz : qloz, hiz = nz ? qloz : qhiz;
         uint32_t isInner = (meta & (meta << 1)) & 0x10101010u;
-        uint32_t innerMask = ((isInner >> 4) << 8) - (isInner >> 4);              // == (isInner >> 4) * 0xff without the quarter-rate v_mul_lo_u32
+        // == (isInner >> 4) * 0xff without the quarter-rate v_mul_lo_u32: the empty asm keeps the compiler from folding shift and
+        // subtraction back into that multiplication (it did: two v_mul_lo_u32 per node visit in the round-3 ISA)
+        uint32_t innerHi = (isInner >> 4) << 8;
+        asm("" : "+v"(innerHi));
+        uint32_t innerMask = innerHi - (isInner >> 4);
         uint32_t bitIndex = (meta ^ (octinv4 & innerMask)) & 0x1F1F1F1Fu;
         uint32_t childBits = (meta >> 5) & 0x07070707u;
 #pragma unroll
@@ -307,7 +311,14 @@ PT_DEV void cwbvh_visit_node(const uint4* __restrict__ nodes, uint32_t nodeOffse
                              uint2& ng, uint2& tg, uint32_t& sp, bool& overflow, ST& st, Counters& cn)
 {
     const uint32_t childNodeIndex = cwbvh_pick_child<STATS>(ng, octinv4, sp, overflow, st, cn);
-    const uint4* np = nodes + (size_t)(nodeOffset + childNodeIndex) * 5;
+    // 32-bit byte offset from the (wave-uniform) base: the loads take base + offset themselves (SGPR base, VGPR offset) instead of a
+    // 64-bit address formed with a quarter-rate v_mad_u64_u32.  PTSetScene refuses node arrays of 4 GiB and more.
+    // (index * 80 as ((index << 2) + index) << 4: written as a product the compiler emits v_mul_lo_u32, quarter rate again; the empty
+    // asm hides that the two operands of the shift-add are the same value)
+    const uint32_t nodeIndex = nodeOffset + childNodeIndex;
+    uint32_t nodeIndexCopy = nodeIndex;
+    asm("" : "+v"(nodeIndexCopy));
+    const uint4* np = (const uint4*)((const char*)nodes + (uint32_t)(((nodeIndexCopy << 2) + nodeIndex) << 4));
     uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
     cwbvh_apply_node<STATS>(o, invDir, octinv4, tmax, n0, n1, n2, n3, n4, ng, tg, cn);
 }
@@ -693,6 +704,62 @@ PT_DEV v4 sample_texture(const DScene& S, int32_t textureIndex, v2 uv, Counters&
     return lerp4(lerp4(p1, p2, uF), lerp4(p3, p4, uF), vF);
 }
 
+// The four texture lookups of a material (base colour, emission, metallic-roughness, occlusion) as TWO memory round trips for
+// all of them -- every wanted descriptor, then every texel -- instead of two per texture one after the other (PT_TEX_BATCH).
+// Same arithmetic per texture as sample_texture (same counters), only the order of the requests differs.
+#ifndef PT_TEX_BATCH
+#define PT_TEX_BATCH 1
+#endif
+template <bool STATS>
+PT_DEV void sample_textures4(const DScene& S, const bool want[4], const int32_t index[4], const v2 uvs[4], v4 out[4], Counters& cn)
+{
+    uint32_t width[4], height[4], offset[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        width[k] = 1u; height[k] = 1u; offset[k] = 0u;
+        if (want[k]) {
+            const uint32_t dsc = (uint32_t)index[k] * 4u;
+            width[k] = S.tex[dsc + 0]; height[k] = S.tex[dsc + 1]; offset[k] = S.tex[dsc + 2];
+            if (STATS) cn.texDescFetches++;
+        }
+    }
+    asm volatile("" : "+v"(width[0]), "+v"(width[1]), "+v"(width[2]), "+v"(width[3]));           // all descriptors requested before the first is used
+    uint32_t px[4][4];
+    float uF[4], vF[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uF[k] = 0.0f; vF[k] = 0.0f;
+        px[k][0] = px[k][1] = px[k][2] = px[k][3] = 0u;
+        if (want[k]) {
+            const float u = pt_wrap01(uvs[k].x), v = pt_wrap01(uvs[k].y);
+            const float tu = u * ((float)width[k] - 1.0f);
+            const float tv = v * ((float)height[k] - 1.0f);
+            const uint32_t tx = pt_f2u(tu), ty = pt_f2u(tv);
+            uF[k] = tu - (float)tx; vF[k] = tv - (float)ty;
+            const uint32_t w1 = width[k] - 1u, h1 = height[k] - 1u;
+            const uint32_t x0 = tx < w1 ? tx : w1, x1 = tx + 1u < w1 ? tx + 1u : w1;
+            const uint32_t y0 = ty < h1 ? ty : h1, y1 = ty + 1u < h1 ? ty + 1u : h1;
+            const uint32_t* base = S.tex + offset[k];
+            px[k][0] = base[y0 * width[k] + x0];
+            px[k][1] = base[y0 * width[k] + x1];
+            px[k][2] = base[y1 * width[k] + x0];
+            px[k][3] = base[y1 * width[k] + x1];
+            if (STATS) cn.texelFetches += 4u;
+        }
+    }
+    asm volatile("" : "+v"(px[0][0]), "+v"(px[1][0]), "+v"(px[2][0]), "+v"(px[3][0]));          // all texels requested before the first is used
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        out[k] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (want[k]) {
+            v4 p[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) p[q] = {pt_unorm8(px[k][q]), pt_unorm8(px[k][q] >> 8), pt_unorm8(px[k][q] >> 16), pt_unorm8(px[k][q] >> 24)};
+            out[k] = lerp4(lerp4(p[0], p[1], uF[k]), lerp4(p[2], p[3], uF[k]), vF[k]);
+        }
+    }
+}
+
 template <bool STATS>
 PT_DEV Material get_material(const DScene& S, int32_t materialIndex, v3 rayDir, const SurfHit& hit, Counters& cn)
 {
@@ -702,9 +769,20 @@ PT_DEV Material get_material(const DScene& S, int32_t materialIndex, v3 rayDir, 
     const bool T = S.hasTextures != 0u;
     v2 uv = hit.uv;
     v4 bco = {d1.x, d1.y, d1.z, d1.w};
+#if PT_TEX_BATCH
+    const bool want[4] = {T && !(d6t1.z < 0.0f), T && !(t2.y < 0.0f), T && !(d6t1.w < 0.0f), T && !(t2.z < 0.0f)};
+    const int32_t tindex[4] = {pt_f2i(d6t1.z), pt_f2i(t2.y), pt_f2i(d6t1.w), pt_f2i(t2.z)};
+    const v2 uvs[4] = {{uv.x * tr.x + tr.z, uv.y * tr.y + tr.w}, uv, uv, uv};
+    v4 texel[4];
+    if (T) sample_textures4<STATS>(S, want, tindex, uvs, texel, cn);
+#endif
     if (T && !(d6t1.z < 0.0f)) {                                          // GetBaseColorOpacity :56-69
+#if PT_TEX_BATCH
+        v4 px = texel[0];
+#else
         v2 tuv = {uv.x * tr.x + tr.z, uv.y * tr.y + tr.w};
         v4 px = sample_texture<STATS>(S, pt_f2i(d6t1.z), tuv, cn);
+#endif
         bco = px * bco;
     }
     Material m;
@@ -714,12 +792,20 @@ PT_DEV Material get_material(const DScene& S, int32_t materialIndex, v3 rayDir, 
     m.alphaCutoff = d2.w;
     m.emission = mk3(d2.x, d2.y, d2.z);
     if (T && !(t2.y < 0.0f)) {                                            // GetEmission :8-21
+#if PT_TEX_BATCH
+        v4 px = texel[1];
+#else
         v4 px = sample_texture<STATS>(S, pt_f2i(t2.y), uv, cn);
+#endif
         m.emission = mk3(px.x, px.y, px.z);
     }
     float metallic = d3.x, rough = d3.y;
     if (T && !(d6t1.w < 0.0f)) {                                          // GetMetallicRoughness :40-54
+#if PT_TEX_BATCH
+        v4 px = texel[2];
+#else
         v4 px = sample_texture<STATS>(S, pt_f2i(d6t1.w), uv, cn);
+#endif
         metallic = px.z;
         rough = px.y * px.y;
     }
@@ -736,7 +822,11 @@ PT_DEV Material get_material(const DScene& S, int32_t materialIndex, v3 rayDir, 
     m.anisotropic = pt_clamp(d4.y, -0.9f, 0.9f);
     m.occlusion = 1.0f;
     if (T && !(t2.z < 0.0f)) {                                            // GetOcclusion :71-82
+#if PT_TEX_BATCH
+        float px = texel[3].x;
+#else
         float px = sample_texture<STATS>(S, pt_f2i(t2.z), uv, cn).x;
+#endif
         m.occlusion = 1.0f + (px - 1.0f);
     }
     float aspect = pt_sqrt(1.0f - m.anisotropic * 0.9f);
