@@ -1,0 +1,242 @@
+"""End-to-end ANALYTIC pins of the shading half of the CPU oracle.
+
+The reference holds no fixtures and its HLSL cannot run here, so these rows cannot be pinned by anything the reference
+produced.  What can be done is to render small constructed scenes whose image has a CLOSED FORM that follows from the
+geometry and from what the shader documents (camera model, light shapes, texture addressing) -- computed below in float64
+with numpy, independently of oracle/pt_oracle.cpp -- and to compare.  Each test names the reference lines it pins.  The
+MI355X kernels inherit every one of them through bit-equality with the oracle (tests/test_gpu_parity.py).
+"""
+import numpy as np
+import pytest
+
+from unity_webgpu_pathtracer_amd import plugin, scenes
+from unity_webgpu_pathtracer_amd.scenes import Camera, Scene, SoupBuilder, pack_material
+
+F32 = np.float32
+NO_LIGHTS = np.zeros((0, 16), dtype=F32)
+NO_TEX = np.zeros(0, dtype=np.uint32)
+
+
+def _render(oracle, s, w, h, **kw):
+    nodes, tris = plugin.build_cwbvh(s.vertices)
+    b = oracle.SceneBuffers(s, nodes, tris)
+    img, _ = oracle.render(b, scenes.frame_params(s, w, h, **kw))
+    return img.astype(np.float64)
+
+
+def _hidden_geometry(sb, material=0):
+    """A BVH needs a triangle: one far behind every camera used here."""
+    sb.quad((-0.01, -0.01, -500.0), (0.02, 0, 0), (0, 0.02, 0), (0, 0, 1), 1, 1, material)
+
+
+def _camera_basis(cam):
+    """Unity conventions, float64: left-handed, right = up x forward (BVHScene / Camera.cameraToWorldMatrix)."""
+    eye = np.asarray(cam.eye, np.float64)
+    fwd = np.asarray(cam.target, np.float64) - eye
+    fwd /= np.linalg.norm(fwd)
+    right = np.cross(np.asarray(cam.up, np.float64), fwd)
+    right /= np.linalg.norm(right)
+    return eye, right, np.cross(fwd, right), fwd
+
+
+def _pixel_directions(cam, w, h):
+    """World direction through the CENTRE of every pixel of a pinhole camera with vertical field of view vfov:
+    pixel (x, y) -> ndc = ((x + 0.5) / w * 2 - 1, (y + 0.5) / h * 2 - 1), y up (PathTracer.compute:52-72, util/camera.hlsl:13-24)."""
+    eye, right, up, fwd = _camera_basis(cam)
+    t = np.tan(np.radians(cam.vfov_deg) / 2)
+    x = ((np.arange(w) + 0.5) / w * 2 - 1) * t * (w / h)
+    y = ((np.arange(h) + 0.5) / h * 2 - 1) * t
+    X, Y = np.meshgrid(x, y)
+    d = fwd[None, None, :] + X[..., None] * right + Y[..., None] * up
+    return eye, d / np.linalg.norm(d, axis=-1, keepdims=True)
+
+
+def _project(cam, w, h, p):
+    """World point -> continuous pixel coordinates (pixel centres at integer + 0.5)."""
+    eye, right, up, fwd = _camera_basis(cam)
+    v = np.asarray(p, np.float64) - eye
+    z = v @ fwd
+    t = np.tan(np.radians(cam.vfov_deg) / 2)
+    return ((v @ right) / z / (t * w / h) + 1) / 2 * w, ((v @ up) / z / t + 1) / 2 * h, z
+
+
+# ---------------------------------------------------------------------------------------
+# R15: the basic sky gradient (util/sky.hlsl:100-112) seen by camera rays (rayDepth 0: intensity 1, util/sky.hlsl:94-96)
+# ---------------------------------------------------------------------------------------
+def test_basic_sky_gradient_closed_form(oracle):
+    sb = SoupBuilder()
+    _hidden_geometry(sb)
+    verts, attrs = sb.finish()
+    cam = Camera(eye=(0, 1, 0), target=(0, 1.6, 1), vfov_deg=70.0)
+    s = Scene("sky", verts, attrs, np.stack([pack_material()]), NO_LIGHTS, NO_TEX, cam, environment_mode=1, environment_intensity=3.0)
+    w, h = 48, 36
+    img = _render(oracle, s, w, h, spp=64, seed=5, max_bounces=1)
+    _, d = _pixel_directions(cam, w, h)
+    a = np.clip(0.5 * (d[..., 1] + 1.0), 0.0, 1.0)
+    blue = np.array([0.5 ** 2.2, 0.7 ** 2.2, 1.0])
+    want = (1.0 - a)[..., None] * np.ones(3) + a[..., None] * blue
+    assert np.abs(img[..., :3] - want).max() < 4e-3            # the gradient moves ~1e-2 per pixel here; 64 jittered samples average to the centre
+    assert (img[..., 3] == 1.0).all()
+
+
+# ---------------------------------------------------------------------------------------
+# R2 + R7: a rectangle light seen directly.  Its image is the perspective projection of the rectangle (camera model), every
+# covered pixel holds the light's emission exactly once (util/pathtrace.hlsl:42-49: no falloff, no cosine), the back face is
+# invisible (util/intersect.hlsl:29-54: dot(normal, dir) < 0), and the pixel-filter jitter is symmetric (PathTracer.compute:31-38,66-72)
+# ---------------------------------------------------------------------------------------
+def _light_scene(center, right, up, size, cam, emission=(5.0, 3.0, 2.0)):
+    sb = SoupBuilder()
+    _hidden_geometry(sb)
+    verts, attrs = sb.finish()
+    light = scenes.pack_rect_light(center, right, up, size, emission)
+    return Scene("light", verts, attrs, np.stack([pack_material()]), np.stack([light]), NO_TEX, cam,
+                 environment_mode=0, environment_color=(0.0, 0.0, 0.0, 1.0))
+
+
+@pytest.mark.parametrize("offset", [(0.0, 0.0), (0.9, -0.5), (-1.3, 0.7)])
+def test_rectangle_light_projects_where_the_camera_model_says(oracle, offset):
+    cam = Camera(eye=(0.5, 1.0, -6.0), target=(0.3, 1.2, 0.0), vfov_deg=40.0)
+    eye, right, up, fwd = _camera_basis(cam)
+    centre = eye + 6.0 * fwd + offset[0] * right + offset[1] * up
+    size = (0.5, 0.3)
+    # pack_rect_light: normal = normalize(cross(u, v)); (right, -up) makes it face the camera (against fwd)
+    s = _light_scene(centre, right, -up, size, cam)
+    w, h = 96, 72
+    img = _render(oracle, s, w, h, spp=64, seed=9, max_bounces=1)
+    lum = img[..., 0]
+    assert lum.max() <= 5.0 + 1e-5 and np.allclose(img[..., 1] * 5.0, img[..., 0] * 3.0, atol=1e-5)        # emission, never scaled
+    px, py, z = _project(cam, w, h, centre)
+    ys, xs = np.mgrid[0:h, 0:w]
+    m = lum.sum()
+    cx, cy = (lum * (xs + 0.5)).sum() / m, (lum * (ys + 0.5)).sum() / m
+    assert abs(cx - px) < 0.08 and abs(cy - py) < 0.08, (cx, px, cy, py)
+    # flux: emission x the rectangle's area in pixels (the plane is parallel to the image plane)
+    pix = 2 * z * np.tan(np.radians(cam.vfov_deg) / 2) / h
+    assert abs(m / 5.0 - size[0] * size[1] / pix ** 2) / (size[0] * size[1] / pix ** 2) < 0.02
+    # the back of the light is not seen
+    back = _render(oracle, _light_scene(centre, right, up, size, cam), w, h, spp=4, seed=9, max_bounces=1)
+    assert back[..., :3].max() == 0.0
+
+
+# ---------------------------------------------------------------------------------------
+# R2: thin lens (util/camera.hlsl:26-40).  A small light at depth z with the focus at ft is imaged as a disc of radius
+# R |1 - ft / z| on the focal plane, R = Aperture / 2, uniformly filled (ConcentricSampleDisk): variance R^2 |1 - ft/z|^2 / 4 per axis
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("depth", [4.0, 6.0, 10.0])
+def test_thin_lens_circle_of_confusion(oracle, depth):
+    ft, aperture = 6.0, 0.3
+    cam = Camera(eye=(0, 0, 0), target=(0, 0, 1), vfov_deg=30.0, aperture=aperture, focal_length=ft)
+    pin = Camera(eye=(0, 0, 0), target=(0, 0, 1), vfov_deg=30.0)
+    size = (0.1, 0.1)
+    w, h = 96, 96
+    ys, xs = np.mgrid[0:h, 0:w]
+
+    def second_moment(c):
+        s = _light_scene((0.0, 0.0, depth), (1, 0, 0), (0, -1, 0), size, c, emission=(1.0, 1.0, 1.0))
+        lum = _render(oracle, s, w, h, spp=1024, seed=21, max_bounces=1)[..., 0]
+        m = lum.sum()
+        cx, cy = (lum * (xs + 0.5)).sum() / m, (lum * (ys + 0.5)).sum() / m
+        return (lum * ((xs + 0.5 - cx) ** 2 + (ys + 0.5 - cy) ** 2)).sum() / m, cx, cy
+
+    v_lens, cx, cy = second_moment(cam)
+    v_pin, _, _ = second_moment(pin)                       # rectangle size + pixel filter + pixel box: common to both
+    assert abs(cx - w / 2) < 0.1 and abs(cy - h / 2) < 0.1
+    pix_at_depth = 2 * depth * np.tan(np.radians(15.0)) / h                 # world size of a pixel at the light's depth
+    r = aperture / 2 * abs(1 - depth / ft) / pix_at_depth                   # blur radius in pixels, seen from the light's plane
+    want = 2 * r * r / 4                                                     # x + y variance of a uniform disc
+    got = v_lens - v_pin
+    # ~2,500 camera samples land on the light per render: the second moments carry ~3 % of sampling noise each
+    if depth == ft:
+        assert abs(got) < 0.08, got                                          # in focus: as sharp as the pinhole
+    else:
+        assert abs(got - want) / want < 0.08, (got, want)
+
+
+# ---------------------------------------------------------------------------------------
+# R8 + R9: texture addressing and bilinear filtering (util/texture.hlsl:25-76) through the emission slot
+# (util/material.hlsl:8-21: the texel REPLACES the emission), on a quad whose uv the attributes interpolate (util/bvh.hlsl:201-215)
+# ---------------------------------------------------------------------------------------
+def test_emission_texture_is_bilinear_in_uv(oracle):
+    rng = np.random.RandomState(3)
+    tw, th = 5, 4
+    texel = rng.randint(0, 256, size=(th, tw, 4)).astype(np.uint32)
+    img_tex = (texel.astype(F32) + F32(0.25)) / F32(255.0)              # pack_textures truncates (uint)(x * 255): + 0.25 keeps every byte
+    tex = scenes.pack_textures([img_tex])
+    assert np.array_equal(tex[4:] & 0xFF, texel[..., 0].reshape(-1))     # row-major from row 0, red in the low byte (CopyTextureData.compute:21-35)
+    sb = SoupBuilder()
+    ext = 2.0
+    sb.quad((-1.0, -1.0, 4.0), (ext, 0, 0), (0, ext, 0), (0, 0, -1), 1, 1, 0)
+    verts, attrs = sb.finish()
+    mat = pack_material(color=(0, 0, 0, 1), roughness=1.0, emission=(1.0, 1.0, 1.0), tex_emission=0)
+    cam = Camera(eye=(0, 0, 0), target=(0, 0, 1), vfov_deg=24.0)
+    s = Scene("tex", verts, attrs, np.stack([mat]), NO_LIGHTS, tex, cam, environment_mode=0, environment_color=(0.0, 0.0, 0.0, 1.0))
+    w, h = 40, 40
+    img = _render(oracle, s, w, h, spp=32, seed=2, max_bounces=1)
+    eye, d = _pixel_directions(cam, w, h)
+    hit = eye + d * (4.0 / d[..., 2])[..., None]
+    u, v = (hit[..., 0] + 1.0) / ext, (hit[..., 1] + 1.0) / ext
+    assert u.min() > 0 and u.max() < 1 and v.min() > 0 and v.max() < 1
+    tu, tv = u * (tw - 1), v * (th - 1)                                   # util/texture.hlsl:50-51
+    tx, ty = np.floor(tu).astype(int), np.floor(tv).astype(int)
+    fu, fv = (tu - tx)[..., None], (tv - ty)[..., None]
+    c = texel.astype(np.float64) / 255.0
+    x1, y1 = np.minimum(tx + 1, tw - 1), np.minimum(ty + 1, th - 1)
+    want = (c[ty, tx] * (1 - fu) + c[ty, x1] * fu) * (1 - fv) + (c[y1, tx] * (1 - fu) + c[y1, x1] * fu) * fv
+    # the footprint of a pixel is ~1/13 of a texel and the filter is piecewise linear: the jittered mean sits at the centre value
+    # except in pixels that straddle a texel boundary (a kink): allow those the kink's worth
+    err = np.abs(img[..., :3] - want[..., :3])
+    assert np.median(err) < 2e-3 and err.max() < 4e-2, (np.median(err), err.max())
+
+
+# ---------------------------------------------------------------------------------------
+# R10 / R11: spot cone and range falloff (util/light.hlsl:60-93) as RATIOS between renders that differ in one light parameter:
+# the BSDF, the geometry and the (absent) 1 / d^2 cancel, what is left is the factor itself
+# ---------------------------------------------------------------------------------------
+def _floor_scene(light):
+    sb = SoupBuilder()
+    sb.quad((-4.0, 0.0, -4.0), (8.0, 0, 0), (0, 0, 8.0), (0, 1, 0), 1, 1, 0)
+    verts, attrs = sb.finish()
+    cam = Camera(eye=(0, 6.0, -0.001), target=(0, 0, 0), up=(0, 0, 1), vfov_deg=50.0)
+    mat = pack_material(color=(0.8, 0.8, 0.8, 1), roughness=1.0)
+    return Scene("floor", verts, attrs, np.stack([mat]), np.stack([light]), NO_TEX, cam, environment_mode=0, environment_color=(0.0, 0.0, 0.0, 1.0))
+
+
+def _floor_points(s, w, h):
+    eye, d = _pixel_directions(s.camera, w, h)
+    return eye + d * (-eye[1] / d[..., 1])[..., None]
+
+
+def test_spot_cone_factor(oracle):
+    pos, fwd = np.array([0.3, 2.0, -0.2]), np.array([0.2, -1.0, 0.1])
+    outer, inner = 70.0, 40.0
+    w, h = 96, 96
+    kw = dict(spp=32, seed=4, max_bounces=1, russian_roulette=False)
+    spot = _render(oracle, _floor_scene(scenes.pack_spot_light(pos, fwd, outer, inner, (4.0, 4.0, 4.0), rng=50.0)), w, h, **kw)[..., 0]
+    point = _render(oracle, _floor_scene(scenes.pack_point_light(pos, (4.0, 4.0, 4.0), rng=50.0)), w, h, **kw)[..., 0]
+    P = _floor_points(_floor_scene(scenes.pack_point_light(pos, (1, 1, 1))), w, h)
+    to = P - pos
+    cos_t = (to / np.linalg.norm(to, axis=-1, keepdims=True)) @ (fwd / np.linalg.norm(fwd))
+    c_out, c_in = np.cos(np.radians(outer) / 2), np.cos(np.radians(inner) / 2)
+    factor = np.clip((cos_t - c_out) / (c_in - c_out), 0.0, 1.0)          # 0 outside the cone, ramp in cos(theta), 1 inside the inner cone
+    assert point.min() > 0
+    ratio = spot / point
+    safe = (np.abs(cos_t - c_out) > 0.01) & (np.abs(cos_t - c_in) > 0.01)  # the pixel filter rounds the two kinks of the ramp
+    assert np.abs(ratio - factor)[safe].max() < 0.04, np.abs(ratio - factor)[safe].max()
+    assert (spot[cos_t < c_out - 0.04] == 0).all() and np.allclose(ratio[cos_t > c_in + 0.04], 1.0, atol=1e-5)      # a few pixels clear of the edges (Gaussian pixel filter)
+
+
+def test_range_falloff_factor(oracle):
+    pos = np.array([0.0, 1.5, 0.0])
+    w, h = 64, 64
+    kw = dict(spp=32, seed=6, max_bounces=1, russian_roulette=False)
+    far = _render(oracle, _floor_scene(scenes.pack_point_light(pos, (4.0, 4.0, 4.0), rng=1e6)), w, h, **kw)[..., 0]
+    near = _render(oracle, _floor_scene(scenes.pack_point_light(pos, (4.0, 4.0, 4.0), rng=3.0)), w, h, **kw)[..., 0]
+    d = np.linalg.norm(_floor_points(_floor_scene(scenes.pack_point_light(pos, (1, 1, 1))), w, h) - pos, axis=-1)
+    r = d / 3.0
+    atten = np.clip(1.0 / (1.0 + 25.0 * r * r) * np.clip((1.0 - r) * 5.0, 0.0, 1.0), 0.0, 1.0)     # util/light.hlsl:66-72
+    atten[d > 3.0] = 0.0
+    assert far.min() > 0
+    ratio = near / far                                                      # at range 1e6 the factor is 1 - O(1e-11)
+    inside = d < 2.9
+    assert np.abs(ratio - atten)[inside].max() < 0.01 * atten[inside].max() + 3e-3
+    assert (near[d > 3.3] == 0).all() and (d > 3.3).sum() > 200
