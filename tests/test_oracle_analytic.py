@@ -240,3 +240,53 @@ def test_range_falloff_factor(oracle):
     inside = d < 2.9
     assert np.abs(ratio - atten)[inside].max() < 0.01 * atten[inside].max() + 3e-3
     assert (near[d > 3.3] == 0).all() and (d > 3.3).sum() > 200
+
+
+# ---------------------------------------------------------------------------------------
+# R1: the running mean of PathTracer.compute:89-98, on a scene whose every sample is the same colour
+# ---------------------------------------------------------------------------------------
+def test_progressive_mean_closed_form(oracle):
+    sb = SoupBuilder()
+    _hidden_geometry(sb)
+    verts, attrs = sb.finish()
+    sky = (0.25, 0.5, 0.75)
+    s = Scene("const", verts, attrs, np.stack([pack_material()]), NO_LIGHTS, NO_TEX, Camera(eye=(0, 0, 0), target=(0, 0, 1)),
+              environment_mode=0, environment_color=sky + (1.0,), environment_intensity=7.0)     # intensity applies from depth 1 on only
+    nodes, tris = plugin.build_cwbvh(s.vertices)
+    b = oracle.SceneBuffers(s, nodes, tris)
+    w, h, n, k = 16, 8, 4, 10
+    first, _ = oracle.render(b, scenes.frame_params(s, w, h, spp=n, current_sample=0))
+    assert np.allclose(first[..., :3], sky, atol=1e-6) and (first[..., 3] == 1).all()
+    acc = np.zeros((h, w, 4), F32)
+    acc[..., :3] = (2.0, 1.0, 0.5)
+    out, _ = oracle.render(b, scenes.frame_params(s, w, h, spp=n, current_sample=k), accumulated=acc)
+    want = (n * np.array(sky) + k * np.array([2.0, 1.0, 0.5])) / (k + n)
+    assert np.allclose(out[..., :3], want, rtol=1e-6) and (out[..., 3] == 1).all()
+
+
+# ---------------------------------------------------------------------------------------
+# PathTracer.compute:76-82: the firefly filter scales a sample down to MaxFireflyLuminance, keeping its colour
+# ---------------------------------------------------------------------------------------
+def test_firefly_filter_clamps_luminance(oracle):
+    cam = Camera(eye=(0, 0, -4.0), target=(0, 0, 0), vfov_deg=20.0)
+    s = _light_scene((0, 0, 0), (1, 0, 0), (0, -1, 0), (6.0, 6.0), cam, emission=(40.0, 20.0, 10.0))       # fills the frame
+    img = _render(oracle, s, 8, 8, spp=4, seed=1, max_bounces=1, firefly=True, max_firefly_luminance=10.0)
+    lum = 0.299 * 40.0 + 0.587 * 20.0 + 0.114 * 10.0
+    assert np.allclose(img[..., :3], np.array([40.0, 20.0, 10.0]) * 10.0 / lum, rtol=1e-5)
+    plain = _render(oracle, s, 8, 8, spp=4, seed=1, max_bounces=1)
+    assert np.allclose(plain[..., :3], [40.0, 20.0, 10.0])
+
+
+# ---------------------------------------------------------------------------------------
+# util/pathtrace.hlsl:120-128: Russian roulette is unbiased -- same mean with and without it
+# ---------------------------------------------------------------------------------------
+def test_russian_roulette_is_unbiased(oracle):
+    s = scenes.cornell_box()
+    nodes, tris = plugin.build_cwbvh(s.vertices)
+    b = oracle.SceneBuffers(s, nodes, tris)
+    means = []
+    for rr in (False, True):
+        img, _ = oracle.render(b, scenes.frame_params(s, 40, 40, spp=192, seed=17, max_bounces=6, russian_roulette=rr))
+        assert not np.isnan(img).any()
+        means.append(img[..., :3].astype(np.float64).mean(axis=(0, 1)))
+    assert np.allclose(means[0], means[1], rtol=0.03), means
