@@ -134,11 +134,16 @@ PT_DEV float rnd(uint32_t& s) { return pt_random_float(&s); }
 typedef const volatile __attribute__((address_space(3))) uint32_t* pt_lds_word;    // an LDS address (32 bits, no flat pointer)
 #define PT_LDS_WORD(var) ((pt_lds_word)(&(var)))
 
+// The LDS part is addressed through an LDS-address-space pointer (32 bits): through a generic `uint2*` the accesses become FLAT
+// instructions as soon as the compiler loses sight of where the pointer came from (the megakernel keeps the struct in scratch).
+typedef uint32_t pt_u2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) pt_u2* pt_lds_u2;
+#define PT_LDS_U2(ptr) ((pt_lds_u2)(ptr))
 template <int LDSN, bool GSPILL = false>
 struct TravStackT {
     static constexpr uint32_t kLds = LDSN;
     static constexpr bool kGlobalSpill = GSPILL;
-    uint2* lds;                 // &smem[0][threadIdx.x]; entry stride = blockDim.x
+    pt_lds_u2 lds;              // &smem[0][threadIdx.x]; entry stride = blockDim.x
     uint32_t stride;
     uint2 spill[GSPILL ? 1 : PT_BVH_STACK_SIZE - LDSN];
     uint2* gbase;               // GSPILL: slab base (wave-uniform)
@@ -155,10 +160,13 @@ PT_DEV size_t spill_row(pt_lds_word gwave)
     return (size_t)(*gwave * 64u + lane);
 }
 
+// The empty asm statements keep the LDS access in a branch of its own.  Without them the compiler merges it with the access to
+// the private overflow array into ONE access through a selected pointer -- a FLAT load / store, which travels the texture-address
+// path even when it resolves to LDS and counts against both memory counters (round 3: the megakernel's stack was all flat).
 template <class ST>
 PT_DEV void stack_push(ST& st, uint32_t sp, uint2 v)
 {
-    if (sp < ST::kLds) st.lds[sp * st.stride] = v;
+    if (sp < ST::kLds) { st.lds[sp * st.stride] = pt_u2{v.x, v.y}; asm volatile("" ::: "memory"); }
     else if (sp < PT_BVH_STACK_SIZE) {
         if (ST::kGlobalSpill) st.gbase[spill_row(st.gwave) * (PT_BVH_STACK_SIZE - ST::kLds) + (sp - ST::kLds)] = v;
         else st.spill[ST::kGlobalSpill ? 0u : sp - ST::kLds] = v;
@@ -167,7 +175,7 @@ PT_DEV void stack_push(ST& st, uint32_t sp, uint2 v)
 template <class ST>
 PT_DEV uint2 stack_pop(ST& st, uint32_t sp)
 {
-    if (sp < ST::kLds) return st.lds[sp * st.stride];
+    if (sp < ST::kLds) { const pt_u2 q = st.lds[sp * st.stride]; uint2 v = make_uint2(q.x, q.y); asm volatile("" : "+v"(v.x), "+v"(v.y)); return v; }
     if (sp < PT_BVH_STACK_SIZE) {
         if (ST::kGlobalSpill) return st.gbase[spill_row(st.gwave) * (PT_BVH_STACK_SIZE - ST::kLds) + (sp - ST::kLds)];
         return st.spill[ST::kGlobalSpill ? 0u : sp - ST::kLds];

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256, PT_MK_MIN_WAVES) void pt_megakernel(DScene S, 
 
     Counters cn = {};
     TravStack st;
-    st.lds = &s_stack[0][tid];
+    st.lds = PT_LDS_U2(&s_stack[0][tid]);
     st.stride = 256u;
 
     PathRegs r;

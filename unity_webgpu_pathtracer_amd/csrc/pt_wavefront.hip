@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256, 4) void pt_wf_trace(DScene S, PTWfBuffers B, u
         v3 o, d;
         fetch_ray(B, slot, kind, o, d);
         TravStack st;
-        st.lds = &s_stack[0][threadIdx.x];
+        st.lds = PT_LDS_U2(&s_stack[0][threadIdx.x]);
         st.stride = 256u;
         HitRecord h;
         h.h.t = PT_FAR_PLANE; h.h.u = 0.0f; h.h.v = 0.0f; h.h.triIndex = 0u;
@@ -278,8 +278,8 @@ PT_DEV void suspend_ray(const PTWfBuffers& B, uint32_t rec, uint32_t slot, uint3
     p[1] = make_uint4(r.tg.x, r.tg.y, pt_asuint(r.hit.t), 0u);
 #pragma unroll
     for (uint32_t e = 0; e < PT_WF_SUSP_STACK_ROWS; ++e) {
-        const uint2 x = st.lds[(2u * e) * st.stride];
-        const uint2 y = (2u * e + 1u < PT_WF_LDS_STACK) ? st.lds[(2u * e + 1u) * st.stride] : make_uint2(0u, 0u);
+        const pt_u2 x = st.lds[(2u * e) * st.stride];
+        const pt_u2 y = (2u * e + 1u < PT_WF_LDS_STACK) ? (pt_u2)st.lds[(2u * e + 1u) * st.stride] : pt_u2{0u, 0u};
         p[2u + e] = make_uint4(x.x, x.y, y.x, y.y);
     }
 }
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(
 
     Counters cn = {};
     TravStackT<PT_WF_LDS_STACK, true> st;
-    st.lds = &s_stack[0][lane];
+    st.lds = PT_LDS_U2(&s_stack[0][lane]);
     st.stride = 64u;
     st.gbase = B.stackSpill;
     st.gwave = PT_LDS_WORD(s_gw);                                                 // slab row = wave * 64 + lane < numSlots
@@ -414,8 +414,8 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_refill(
                     rs.hit.t = pt_asfloat(b.z);
 #pragma unroll
                     for (uint32_t e = 0; e < PT_WF_SUSP_STACK_ROWS; ++e) {
-                        st.lds[(2u * e) * 64u] = make_uint2(er[e].x, er[e].y);
-                        if (2u * e + 1u < PT_WF_LDS_STACK) st.lds[(2u * e + 1u) * 64u] = make_uint2(er[e].z, er[e].w);
+                        st.lds[(2u * e) * 64u] = pt_u2{er[e].x, er[e].y};
+                        if (2u * e + 1u < PT_WF_LDS_STACK) st.lds[(2u * e + 1u) * 64u] = pt_u2{er[e].z, er[e].w};
                     }
                     have = true;
                 }
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(64 * WAVES, PT_WF_TLAS_MIN_WAVES) void pt_wf_trace_
 
     Counters cn = {};
     TravStackT<kBlasLds, true> st;
-    st.lds = &s_stack[wv][0][lane];
+    st.lds = PT_LDS_U2(&s_stack[wv][0][lane]);
     st.stride = 64u;
     st.gbase = B.stackSpill;
     st.gwave = PT_LDS_WORD(s_gw[wv]);
@@ -895,7 +895,7 @@ __global__ __launch_bounds__(64, PT_WF_TRACE_MIN_WAVES) void pt_wf_trace_persist
 
     Counters cn = {};
     TravStackT<PT_WF_LDS_STACK, true> st;
-    st.lds = &s_stack[0][lane];
+    st.lds = PT_LDS_U2(&s_stack[0][lane]);
     st.stride = 64u;
     st.gbase = B.stackSpill;
     __shared__ uint32_t s_gw;
@@ -1244,7 +1244,7 @@ __global__ __launch_bounds__(64, PT_WF_FUSED_WAVES) void pt_wf_fused(DScene S, P
         {
             Counters cn = {};
             TravStackT<PT_WF_LDS_STACK, true> st;
-            st.lds = &s_stack[0][lane];
+            st.lds = PT_LDS_U2(&s_stack[0][lane]);
             st.stride = 64u;
             st.gbase = B.stackSpill;
             st.gwave = PT_LDS_WORD(s_gw);
@@ -1278,8 +1278,8 @@ __global__ __launch_bounds__(64, PT_WF_FUSED_WAVES) void pt_wf_fused(DScene S, P
 #pragma unroll
                 for (uint32_t e = 0; e < PT_WF_SUSP_STACK_ROWS; ++e) {
                     const uint4 er = s_susp[lane][2u + e];
-                    st.lds[(2u * e) * 64u] = make_uint2(er.x, er.y);
-                    if (2u * e + 1u < PT_WF_LDS_STACK) st.lds[(2u * e + 1u) * 64u] = make_uint2(er.z, er.w);
+                    st.lds[(2u * e) * 64u] = pt_u2{er.x, er.y};
+                    if (2u * e + 1u < PT_WF_LDS_STACK) st.lds[(2u * e + 1u) * 64u] = pt_u2{er.z, er.w};
                 }
                 have = true;
             }
@@ -1372,8 +1372,8 @@ __global__ __launch_bounds__(64, PT_WF_FUSED_WAVES) void pt_wf_fused(DScene S, P
                         s_susp[rec][1] = make_uint4(rs.tg.x, rs.tg.y, pt_asuint(rs.hit.t), 0u);
 #pragma unroll
                         for (uint32_t e = 0; e < PT_WF_SUSP_STACK_ROWS; ++e) {
-                            const uint2 x = st.lds[(2u * e) * 64u];
-                            const uint2 y = (2u * e + 1u < PT_WF_LDS_STACK) ? st.lds[(2u * e + 1u) * 64u] : make_uint2(0u, 0u);
+                            const pt_u2 x = st.lds[(2u * e) * 64u];
+                            const pt_u2 y = (2u * e + 1u < PT_WF_LDS_STACK) ? (pt_u2)st.lds[(2u * e + 1u) * 64u] : pt_u2{0u, 0u};
                             s_susp[rec][2u + e] = make_uint4(x.x, x.y, y.x, y.y);
                         }
                         atomicOr(&s_pend[pn][local >> 6][(local >> 5) & 1u], 1u << (local & 31u));
@@ -1840,7 +1840,7 @@ __global__ __launch_bounds__(256, 2) void pt_wf_cleanup(DScene S, PTFrameParams 
                 r.light.dir = xyz(B.ray[2][2u * slot + 1u]);
             }
             TravStack st;
-            st.lds = &s_stack[0][threadIdx.x];
+            st.lds = PT_LDS_U2(&s_stack[0][threadIdx.x]);
             st.stride = 256u;
             while (r.state != PS_DONE) {
                 HitRecord ch;
