@@ -1142,7 +1142,7 @@ __global__ __launch_bounds__(PT_WF_SHADE_BLOCK, PT_WF_SHADE_MIN_WAVES) void pt_w
 
 // add a phase's counters to the wave's LDS totals (one wave per workgroup; 16 words, PTStats order)
 template <bool STATS>
-PT_DEV void counters_to_lds(const Counters& cn, volatile uint32_t* tot, uint32_t lane)
+PT_DEV void counters_to_lds(const Counters& cn, pt_lds_u32 tot, uint32_t lane)
 {
     uint32_t vals[PT_NUM_COUNTERS];
     counters_to_array(cn, vals);
@@ -1176,8 +1176,8 @@ __global__ __launch_bounds__(64, PT_WF_FUSED_WAVES) void pt_wf_fused(DScene S, P
     const uint32_t lane = threadIdx.x;
     const uint32_t ctxBase = blockIdx.x * (K * 64u);                 // context = ctxBase + group * 64 + lane
     pt_lds_u32 xchg = (pt_lds_u32)&s_xchg[0];
-    volatile uint32_t* pix = &s_pix[0][0];
-    volatile uint32_t* cnt = s_cnt;
+    pt_lds_u32 pix = (pt_lds_u32)&s_pix[0][0];
+    pt_lds_u32 cnt = (pt_lds_u32)&s_cnt[0];
 #pragma unroll
     for (uint32_t k = 0; k < K; ++k) {
         s_pix[k][lane] = PT_WF_NO_PIXEL;
