@@ -1,7 +1,8 @@
 #!/bin/bash
+# usage: [A_EXTRA=""] tools/experiments/resources.sh [-D flags]   (A_EXTRA: the extra flags of the default schedule's translation unit, csrc/Makefile; empty = the other one)
 # usage: tools/experiments/resources.sh [-D flags]  -> per-kernel VGPRs / scratch / spills / occupancy of pt_wavefront.hip
 cd "$(dirname "$0")/../../unity_webgpu_pathtracer_amd/csrc"
-FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fvisibility=hidden -I../../include -Wno-unused-function -Wno-unused-value -mllvm -amdgpu-sched-strategy=max-memory-clause"
+FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fvisibility=hidden -I../../include -Wno-unused-function -Wno-unused-value -mllvm -amdgpu-sched-strategy=max-memory-clause -mllvm -amdgpu-use-amdgpu-trackers=1 ${A_EXTRA--mllvm -enable-post-misched=false}"
 hipcc --offload-arch=gfx950 $FLAGS "$@" -c ${SRC:-pt_wavefront.hip} -o /tmp/res_$$.o -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c '
 import re, sys
 cur = None

@@ -5,6 +5,10 @@
 // (PathTracer.cs:226-252) and the ping-pong frame bookkeeping (PathTracer.cs:246-247, 268-272).
 // There is NO CPU fallback: without a HIP device PTCreate fails with PT_ERR_NO_DEVICE.
 #include "pt_launch.h"
+hipError_t pt_launch_wavefront_b(const DScene& S, const PTFrameParams& P, const PTBatch& batch, const float4* accumulated, float4* output,
+                                 const PTTileMap& tm, const PTWfBuffers& B, unsigned long long* gstats, bool fullStats,
+                                 hipStream_t stream, hipEvent_t orderAfter, bool zeroOutputFirst,
+                                 uint32_t* launchesOut, int traceVariant, uint32_t iterationsOverride);
 
 #include <dlfcn.h>
 
@@ -462,7 +466,10 @@ int render_to(PTContext* c, const PTFrameParams* hostParams, float4* dOut, const
             HIP_TRY(hipEventRecord(set.callEv, c->stream));
             if (c->profiling && j == 0u) HIP_TRY(hipEventRecord(ep.start, set.stream));
             uint32_t n = 0;
-            HIP_TRY(pt_launch_wavefront(c->scene, *p, batch, dAcc, dOut, tmj, set.wf, c->dStats, c->statsLevel > 0, set.stream, set.callEv,
+            // the default schedule's kernels (refill trace + shade) come from the translation unit built without the post-RA scheduler,
+            // HAS_TLAS, the fused persistent kernel and the other schedules from the one built with it (csrc/Makefile)
+            const bool tuA = schedule == 1 && c->scene.hasTlas == 0u;
+            HIP_TRY((tuA ? pt_launch_wavefront : pt_launch_wavefront_b)(c->scene, *p, batch, dAcc, dOut, tmj, set.wf, c->dStats, c->statsLevel > 0, set.stream, set.callEv,
                                         c->world > 1 && !zeroOnce, &n, schedule == 4 ? 4 : (schedule == 1 ? 2 : (schedule == 2 ? 1 : 0)), c->wfIterations));
             launches += n;
             if (c->profiling && j + 1u == S) HIP_TRY(hipEventRecord(ep.stop, set.stream));

@@ -155,6 +155,11 @@ __host__ __device__ inline void pt_batch_pick(const PTBatch& b, uint32_t j, uint
     for (uint32_t k = 1; k < PT_MAX_BATCH; ++k) if (j == k) { seedRoot = b.seedRoot[k]; currentSample = b.currentSample[k]; }
 }
 
+// pt_wavefront.hip is compiled twice with different scheduler flags (csrc/Makefile): the translation unit built with -DPT_WF_TU_B
+// exports the same launcher under the name pt_launch_wavefront_b
+#ifdef PT_WF_TU_B
+#define pt_launch_wavefront pt_launch_wavefront_b
+#endif
 hipError_t pt_launch_wavefront(const DScene& S, const PTFrameParams& P, const PTBatch& batch, const float4* accumulated, float4* output,
                                const PTTileMap& tm, const PTWfBuffers& B, unsigned long long* gstats, bool fullStats,
                                hipStream_t stream, hipEvent_t orderAfter, bool zeroOutputFirst,
