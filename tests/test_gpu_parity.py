@@ -737,3 +737,30 @@ def test_all_keywords_together(oracle, schedule):
     assert nbad == 0
     _stats_equal(pt.stats(), st, ALL_COUNTERS)
     pt.close()
+
+
+def _analytic_scenes():
+    """The constructed scenes of tests/test_oracle_analytic.py (closed-form images on the oracle): thin lens, a rectangle light seen
+    directly, spot and point lights with a short range, an emission texture -- through the kernels, bit for bit."""
+    import test_oracle_analytic as A
+    cam = scenes.Camera(eye=(0, 0, 0), target=(0, 0, 1), vfov_deg=30.0, aperture=0.3, focal_length=6.0)
+    yield "thin lens", A._light_scene((0.0, 0.0, 4.0), (1, 0, 0), (0, -1, 0), (0.4, 0.4), cam, emission=(1.0, 1.0, 1.0)), 64, 64, 8
+    yield "spot light", A._floor_scene(scenes.pack_spot_light((0.3, 2.0, -0.2), (0.2, -1.0, 0.1), 70.0, 40.0, (4.0, 4.0, 4.0), rng=50.0)), 64, 64, 4
+    yield "point light, short range", A._floor_scene(scenes.pack_point_light((0.0, 1.5, 0.0), (4.0, 4.0, 4.0), rng=3.0)), 64, 64, 4
+
+
+@pytest.mark.parametrize("schedule", [0, 1, 4])
+def test_analytic_scenes_bit_exact(oracle, schedule):
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    for what, s, w, h, spp in _analytic_scenes():
+        pt = PathTracer(s, width=w, height=h, samplesPerPass=spp, schedule=schedule, maxRayBounces=2)
+        pt.set_stats_level(1)
+        p = pt.params(seed=0xA11CE)
+        pt.render_pass(p)
+        gpu = pt.readback()
+        ref, st = _oracle_frame(oracle, pt, p, shadow_any_hit=True)
+        _, nbad = _compare(gpu, ref, what)
+        assert nbad == 0
+        _stats_equal(pt.stats(), st, ALL_COUNTERS)
+        pt.close()
