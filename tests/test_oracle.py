@@ -541,3 +541,22 @@ def test_environment_regression_frame(oracle):
     assert np.array_equal(img.view(np.uint32), g["frame"].view(np.uint32))
     d = st.as_dict()
     assert [d[k] for k in g["stat_names"]] == g["stats"].tolist()
+
+
+def test_oracle_is_compiler_independent():
+    """The canonical arithmetic (include/ptmi_math.h) does not depend on who compiles it: the restatement built
+    by clang at -O1 without -mfma (oracle/Makefile `clang`) renders the regression frames -- every lobe, light type, texture slot,
+    the thin lens, the environment map -- to the same bits and counters as the g++ -O2 -mavx2 -mfma build the goldens were made with."""
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    clang = os.environ.get("CLANGXX", "/opt/rocm/lib/llvm/bin/clang++")
+    if not os.path.exists(clang) and shutil.which("clang++") is None:
+        pytest.skip("no clang++")
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "clang"] + ([] if os.path.exists(clang) else ["CLANGXX=clang++"]),
+                          stdout=subprocess.DEVNULL)
+    env = dict(os.environ, PT_ORACLE_LIB=os.path.join(root, "oracle", "_build", "liboracle_clang.so"))
+    out = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", os.path.join(root, "tests", "test_oracle.py"),
+                          "-k", "test_regression_frames or test_environment_regression_frame"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "2 passed" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
