@@ -462,3 +462,120 @@ def test_eval_brdf_pointwise_against_second_transcription(oracle, mi):
         assert err_f[ok].max() < 2e-3 and err_p[ok].max() < 2e-3, (mi, err_f[ok].max(), err_p[ok].max(), int(np.argmax(np.where(ok, err_f, 0))))
         # and the typical agreement is at the level of fp32 rounding
         assert np.median(err_f[ok]) < 2e-6 and np.median(err_p[ok]) < 2e-6
+
+
+# ---------------------------------------------------------------------------------------
+# R3 + R13: SampleBRDF pointwise.  The PCG recurrence of util/random.hlsl:5-16 in uint32 numpy gives the three draws of every call
+# (r1, r2 first, r3 after the lobe probabilities: util/brdf.hlsl:244-245,287); the lobe pick and the sampled direction follow in float64
+# from util/brdf.hlsl:240-335 and util/sampling.hlsl:20-33,56-74,137-146 -- a second transcription again.  Compared with the direction the
+# oracle draws for the same RNG chain.
+# ---------------------------------------------------------------------------------------
+def _pcg_chain(state, count):
+    out = np.zeros(count, np.float64)
+    s = np.uint32(state)
+    with np.errstate(over="ignore"):
+        for i in range(count):
+            old = np.uint32(s + np.uint32(747796405) + np.uint32(2891336453))
+            word = np.uint32((np.uint32(old >> np.uint32((old >> np.uint32(28)) + np.uint32(4))) ^ old) * np.uint32(277803737))
+            s = np.uint32((word >> np.uint32(22)) ^ word)
+            out[i] = float(np.float32(s)) / 4294967296.0          # (float)state / (float)0xffffffffu, the divisor rounds to 2^32
+    return out
+
+
+def _np_sample_dirs(md, V, N, r):
+    """r: (n, 3) draws.  Returns world directions (n, 3), lobe ids (n,) and the distance of r3 to the nearest lobe boundary."""
+    md = md.astype(np.float64)
+    base, opacity = md[0:3], md[3]
+    metallic, rough = md[8], max(md[9], 0.001)
+    ior = min(max(md[11], 1.001), 2.0)
+    aniso = min(max(md[13], -0.9), 0.9)
+    spec_tint, clearcoat = md[15], md[19]
+    cc_rough = 0.1 + md[20] * (0.001 - 0.1)
+    spec_trans = 1.0 - min(max(opacity, 0.0), 1.0)
+    aspect = np.sqrt(1.0 - aniso * 0.9)
+    ax, ay = max(0.001, rough / aspect), max(0.001, rough * aspect)
+    eta = 1.0 / ior if (-V @ N) < 0.0 else ior
+    k = 1.0 / max(1.0 + N[2], 0.00001)
+    a_, b_ = N[1] * k, N[1] * N[1] * k
+    c_ = -N[0] * a_
+    X = np.array([N[2] + b_, c_, -N[0]]); X /= np.linalg.norm(X)
+    Y = np.array([c_, 1.0 - b_, -N[1]]); Y /= np.linalg.norm(Y)
+    Vl = np.array([V @ X, V @ Y, V @ N])
+    lum = lambda c: c[0] * 0.299 + c[1] * 0.587 + c[2] * 0.114
+    lb = lum(base)
+    ctint = base / lb if lb > 0 else np.ones(3)
+    F0 = ((1.0 - eta) / (1.0 + eta)) ** 2
+    Cspec0 = F0 * (1.0 + spec_tint * (ctint - 1.0))
+    sw = min(max(1.0 - Vl[2], 0.0), 1.0) ** 5
+    diel_wt, metal_wt, glass_wt = (1.0 - metallic) * (1.0 - spec_trans), metallic, (1.0 - metallic) * spec_trans
+    pr = np.array([diel_wt * lb, diel_wt * lum(Cspec0 + sw * (1.0 - Cspec0)), metal_wt * lum(base + sw * (1.0 - base)), glass_wt, 0.25 * clearcoat])
+    pr /= pr.sum()
+    cdf = np.cumsum(pr)
+    r1, r2, r3 = r[:, 0], r[:, 1], r[:, 2]
+    lobe = np.where(r3 < cdf[0], 0, np.where(r3 < cdf[2], 1, np.where(r3 < cdf[3], 2, 3)))
+    margin = np.abs(r3[:, None] - np.array([cdf[0], cdf[2], cdf[3]])[None, :]).min(axis=1)
+    n = r.shape[0]
+    with np.errstate(all="ignore"):
+        # diffuse
+        rr, ph = np.sqrt(r1), 2 * np.pi * r2
+        dx, dy = rr * np.cos(ph), rr * np.sin(ph)
+        Ld = np.stack([dx, dy, np.sqrt(np.maximum(0.0, 1.0 - dx * dx - dy * dy))], -1)
+        # GGX VNDF
+        Vh = np.array([ax * Vl[0], ay * Vl[1], Vl[2]]); Vh /= np.linalg.norm(Vh)
+        lensq = Vh[0] ** 2 + Vh[1] ** 2
+        T1 = np.array([-Vh[1], Vh[0], 0.0]) / np.sqrt(lensq) if lensq > 0 else np.array([1.0, 0.0, 0.0])
+        T2 = np.cross(Vh, T1)
+        t1, t2 = rr * np.cos(ph), rr * np.sin(ph)
+        s = 0.5 * (1.0 + Vh[2])
+        t2 = (1.0 - s) * np.sqrt(1.0 - t1 * t1) + s * t2
+        Nh = t1[:, None] * T1 + t2[:, None] * T2 + np.sqrt(np.maximum(0.0, 1.0 - t1 * t1 - t2 * t2))[:, None] * Vh
+        Hg = np.stack([ax * Nh[:, 0], ay * Nh[:, 1], np.maximum(0.0, Nh[:, 2])], -1)
+        Hg /= np.linalg.norm(Hg, axis=-1, keepdims=True)
+        VdH = Hg @ Vl
+        refl = lambda H: 2.0 * (H @ Vl)[:, None] * H - Vl                           # reflect(-V, H)
+        Lr = refl(Hg); Lr /= np.linalg.norm(Lr, axis=-1, keepdims=True)
+        # glass: Fresnel picks reflection or refraction with the rescaled r3
+        s2 = eta * eta * (1.0 - VdH * VdH)
+        ct = np.sqrt(np.maximum(1.0 - s2, 0.0))
+        ci = np.abs(VdH)
+        Fg = np.where(s2 > 1.0, 1.0, 0.5 * (((eta * ct - ci) / (eta * ct + ci)) ** 2 + ((eta * ci - ct) / (eta * ci + ct)) ** 2))
+        r3g = (r3 - cdf[2]) / (cdf[3] - cdf[2])
+        Hs = np.where((Hg[:, 2] < 0.0)[:, None], -Hg, Hg)
+        ndi = -(Hs @ Vl)                                                              # dot(n, i) with i = -V
+        kk = 1.0 - eta * eta * (1.0 - ndi * ndi)
+        Lt = np.where((kk < 0.0)[:, None], 0.0, eta * (-Vl)[None, :] - (eta * ndi + np.sqrt(np.maximum(kk, 0.0)))[:, None] * Hs)
+        Lt /= np.linalg.norm(Lt, axis=-1, keepdims=True)
+        Lgr = refl(Hs); Lgr /= np.linalg.norm(Lgr, axis=-1, keepdims=True)
+        Lg = np.where((r3g < Fg)[:, None], Lgr, Lt)
+        gmargin = np.abs(r3g - Fg)
+        # clearcoat GTR1
+        a = max(0.001, cc_rough); a2 = a * a
+        cth = np.sqrt((1.0 - a2 ** (1.0 - r2)) / (1.0 - a2))
+        sth = np.clip(np.sqrt(1.0 - cth * cth), 0.0, 1.0)
+        phc = r1 * 2 * np.pi
+        Hc = np.stack([sth * np.cos(phc), sth * np.sin(phc), cth], -1)
+        Lc = refl(Hc); Lc /= np.linalg.norm(Lc, axis=-1, keepdims=True)
+    Ll = np.where((lobe == 0)[:, None], Ld, np.where((lobe == 1)[:, None], Lr, np.where((lobe == 2)[:, None], Lg, Lc)))
+    margin = np.where(lobe == 2, np.minimum(margin, gmargin), margin)
+    return Ll[:, 0:1] * X + Ll[:, 1:2] * Y + Ll[:, 2:3] * N, lobe, margin
+
+
+@pytest.mark.parametrize("mi", range(len(_POINTWISE_MATERIALS)))
+def test_sample_brdf_pointwise_against_second_transcription(oracle, mi):
+    import ctypes as C
+    lib = oracle.load_oracle()
+    md = np.ascontiguousarray(pack_material(**_POINTWISE_MATERIALS[mi]), dtype=F32)
+    n, seed = 1500, 0xBEEF00 + mi
+    draws = _pcg_chain(seed, 3 * n).reshape(n, 3)
+    for Nv, Vv in (((0.0, 0.0, 1.0), (0.3, 0.2, 0.9)), ((0.3, -0.5, 0.8), (0.7, 0.1, 0.4))):
+        N = np.ascontiguousarray((np.array(Nv, np.float64) / np.linalg.norm(Nv)).astype(F32))
+        V = np.ascontiguousarray((np.array(Vv) / np.linalg.norm(Vv)).astype(F32))
+        st = C.c_uint32(seed)
+        Lo = np.zeros((n, 3), F32)
+        fp = np.zeros((n, 4), F32)
+        lib.oracle_sample_brdf_batch(md.ctypes.data, V.ctypes.data, N.ctypes.data, C.c_float(0.0), C.byref(st), C.c_uint64(n), Lo.ctypes.data, fp.ctypes.data)
+        want, lobe, margin = _np_sample_dirs(md, V.astype(np.float64), N.astype(np.float64), draws)
+        ok = (margin > 1e-4) & np.isfinite(want).all(axis=-1) & np.isfinite(Lo).all(axis=-1)      # a draw on a lobe boundary may fall either way in fp32
+        assert ok.sum() > 0.97 * np.isfinite(Lo).all(axis=-1).sum()
+        err = np.abs(Lo.astype(np.float64) - want).max(axis=-1)
+        assert err[ok].max() < 5e-4 and np.median(err[ok]) < 1e-6, (mi, err[ok].max(), np.median(err[ok]), np.bincount(lobe, minlength=4))
