@@ -669,3 +669,42 @@ def test_uniform_sky_one_bounce_closed_form(oracle, mat):
         got.append(img[y - 1:y + 2, x - 1:x + 2, :3].mean(axis=(0, 1)))                # 3 x 3 pixels: the integrand varies slowly across them
     got, want = np.array(got), np.array(want)
     assert np.abs(got / want - 1.0).max() < 0.025, got / want
+
+
+# ---------------------------------------------------------------------------------------
+# R10 + R11 + R12: a floor under a point / spot light, one bounce.  No area to integrate: SampleOneLight reports pdf 0, EvalLight divides
+# by 1 (util/light.hlsl:25-45,96-104), so a pixel is emission x range falloff x cone factor x f(V, direction) -- no inverse square
+# law -- with f from the float64 transcription; the bounce ray leaves the scene into a black sky.
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["point", "spot"])
+def test_point_and_spot_light_closed_form(oracle, kind):
+    pos, fwd, Le, rng_ = np.array([0.4, 1.8, -0.3]), np.array([0.1, -1.0, 0.2]), np.array([3.0, 2.5, 2.0]), 6.0
+    outer, inner = 80.0, 50.0
+    light = scenes.pack_point_light(pos, Le, rng=rng_) if kind == "point" else scenes.pack_spot_light(pos, fwd, outer, inner, Le, rng=rng_)
+    s = _floor_scene(light)
+    s.materials = np.stack([pack_material(color=(0.7, 0.6, 0.8, 1), roughness=0.55, metallic=0.3)])
+    w = h = 96
+    img = _render(oracle, s, w, h, spp=48, seed=8, max_bounces=1, russian_roulette=False)
+    eye, d = _pixel_directions(s.camera, w, h)
+    P = (eye + d * (-eye[1] / d[..., 1])[..., None]).reshape(-1, 3)
+    Vv = (-d).reshape(-1, 3)
+    to = pos - P
+    dist = np.linalg.norm(to, axis=-1)
+    wdir = to / dist[:, None]
+    f, _ = _np_eval_brdf(s.materials[0], Vv, np.array([0.0, 1.0, 0.0]), wdir)
+    r = dist / rng_
+    atten = np.where(dist > rng_, 0.0, np.clip(1.0 / (1.0 + 25.0 * r * r) * np.clip((1.0 - r) * 5.0, 0.0, 1.0), 0.0, 1.0))
+    cone = np.ones_like(dist)
+    if kind == "spot":
+        cos_t = (-wdir) @ (fwd / np.linalg.norm(fwd))
+        c_out, c_in = np.cos(np.radians(outer) / 2), np.cos(np.radians(inner) / 2)
+        cone = np.clip((cos_t - c_out) / (c_in - c_out), 0.0, 1.0)
+        smooth = (np.abs(cos_t - c_out) > 0.03) & (np.abs(cos_t - c_in) > 0.03)             # away from the two kinks of the ramp
+    else:
+        smooth = np.ones_like(dist, bool)
+    want = Le[None, :] * (atten * cone)[:, None] * f
+    got = img[..., :3].reshape(-1, 3)
+    lit = smooth & (want.max(axis=-1) > 1e-3)
+    assert lit.sum() > 150
+    rel = np.abs(got[lit] - want[lit]).max(axis=-1) / want[lit].max(axis=-1)
+    assert np.median(rel) < 6e-3 and rel.max() < 0.10, (np.median(rel), rel.max())          # what is left is the pixel filter over a sloped integrand (the cone's ramp)
