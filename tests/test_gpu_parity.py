@@ -764,3 +764,72 @@ def test_analytic_scenes_bit_exact(oracle, schedule):
         assert nbad == 0
         _stats_equal(pt.stats(), st, ALL_COUNTERS)
         pt.close()
+
+
+def _fuzz_scene(seed):
+    """A random small scene: every material parameter drawn over its whole range (extremes included), random lights of all three
+    types, random textures in random slots, random camera with or without a lens, one of the three sky settings."""
+    rng = np.random.RandomState(seed)
+    pick = lambda lo, hi: float(rng.choice([lo, hi, rng.uniform(lo, hi), rng.uniform(lo, hi)]))
+    n_tex = int(rng.randint(0, 4))
+    images = [rng.uniform(0, 1, size=(int(rng.choice([1, 2, 5, 16])), int(rng.choice([1, 3, 8, 16])), 4)).astype(np.float32) for _ in range(n_tex)]
+    tex = scenes.pack_textures(images)
+    tslot = lambda: int(rng.randint(0, n_tex)) if n_tex and rng.rand() < 0.5 else -1
+    mats = []
+    for _ in range(int(rng.randint(2, 7))):
+        mats.append(scenes.pack_material(
+            color=(pick(0, 1), pick(0, 1), pick(0, 1), pick(0, 1)), transmission=pick(0, 1) if rng.rand() < 0.3 else 0.0,
+            emission=tuple(rng.uniform(0, 3, 3)) if rng.rand() < 0.2 else (0, 0, 0), metallic=pick(0, 1), roughness=pick(0, 1),
+            ior=pick(0.5, 2.5), alpha_mode=int(rng.randint(0, 3)), alpha_cutoff=pick(0, 1), anisotropic=pick(-1, 1), specular_tint=pick(0, 1),
+            sheen=pick(0, 1), sheen_tint=pick(0, 1), subsurface=pick(0, 1), clearcoat=pick(0, 1), clearcoat_gloss=pick(0, 1),
+            tex_base=tslot(), tex_mr=tslot(), tex_emission=tslot(), tex_occlusion=tslot(),
+            uv_scale=(pick(0.5, 4), pick(0.5, 4)), uv_offset=(pick(-2, 2), pick(-2, 2))))
+    mats = np.stack(mats)
+    sb = scenes.SoupBuilder()
+    sb.quad((-4, 0, -4), (8, 0, 0), (0, 0, 8), (0, 1, 0), 3, 3, 0)
+    sb.quad((-4, 0, 4), (8, 0, 0), (0, 5, 0), (0, 0, -1), 2, 2, int(rng.randint(0, len(mats))))
+    for _ in range(int(rng.randint(2, 6))):
+        c = (rng.uniform(-2.5, 2.5), rng.uniform(0.3, 1.5), rng.uniform(-1.5, 2.5))
+        if rng.rand() < 0.6:
+            sb.uv_sphere(c, rng.uniform(0.2, 0.7), 10, 6, int(rng.randint(0, len(mats))))
+        else:
+            sb.quad(c, (rng.uniform(0.5, 2), 0, rng.uniform(-0.5, 0.5)), (0, rng.uniform(0.5, 2), rng.uniform(-0.5, 0.5)), (0, 0.2, -1), 2, 2, int(rng.randint(0, len(mats))))
+    verts, attrs = sb.finish()
+    lights = []
+    for _ in range(int(rng.randint(0, 4))):
+        k = int(rng.randint(0, 3))
+        p = (rng.uniform(-3, 3), rng.uniform(2, 4.5), rng.uniform(-3, 3))
+        col = tuple(rng.uniform(1, 20, 3))
+        if k == 0:
+            lights.append(scenes.pack_rect_light(p, (1, 0, 0), (0, 0, 1), (rng.uniform(0.3, 2), rng.uniform(0.3, 2)), col, rng=pick(3, 50)))
+        elif k == 1:
+            lights.append(scenes.pack_point_light(p, col, rng=pick(3, 20)))
+        else:
+            lights.append(scenes.pack_spot_light(p, (rng.uniform(-1, 1), -1.0, rng.uniform(-1, 1)), rng.uniform(30, 120), rng.uniform(5, 30), col, rng=pick(3, 20)))
+    lights = np.stack(lights) if lights else np.zeros((0, 16), np.float32)
+    lens = rng.rand() < 0.4
+    cam = scenes.Camera(eye=(rng.uniform(-1, 1), rng.uniform(1.5, 3), -5.5), target=(rng.uniform(-0.5, 0.5), 0.7, 0.5), vfov_deg=rng.uniform(25, 70),
+                        aperture=rng.uniform(0.02, 0.3) if lens else 0.0, focal_length=rng.uniform(3, 8) if lens else 0.0)
+    mode = int(rng.randint(0, 2))
+    return scenes.Scene(f"fuzz{seed}", verts, attrs, mats, lights, tex, cam, environment_mode=mode,
+                        environment_color=tuple(rng.uniform(0, 1.5, 3)) + (1.0,), environment_intensity=pick(0, 2))
+
+
+@pytest.mark.parametrize("schedule", [0, 1, 4])
+def test_fuzzed_scenes_bit_exact(oracle, schedule):
+    """Thirty-two random scenes (materials over their whole parameter ranges, all light types, textures in every slot, lens on / off, both sky
+    modes), 48 x 32 at 3 spp with Russian roulette and the firefly filter on every other one: frames and all counters equal the oracle's."""
+    for seed in range(32):
+        s = _fuzz_scene(1000 + seed)
+        pt = PathTracer(s, width=48, height=32, samplesPerPass=3, schedule=schedule, maxRayBounces=1 + seed % 5)
+        pt.set_stats_level(1)
+        p = scenes.frame_params(s, 48, 32, spp=3, seed=0xF00D + seed, max_bounces=1 + seed % 5, russian_roulette=seed % 2 == 0,
+                                firefly=seed % 2 == 1, max_firefly_luminance=4.0)
+        pt.render_pass(p)
+        gpu = pt.readback()
+        ref, st = _oracle_frame(oracle, pt, p, shadow_any_hit=True)
+        nan_g, nan_r = np.isnan(gpu), np.isnan(ref)
+        assert np.array_equal(nan_g, nan_r), f"fuzz {seed}: NaN pattern differs"
+        assert np.array_equal(gpu.view(np.uint32), ref.view(np.uint32)), f"fuzz {seed}: {int((gpu.view(np.uint32) != ref.view(np.uint32)).any(axis=-1).sum())} pixels differ"
+        _stats_equal(pt.stats(), st, ALL_COUNTERS)
+        pt.close()
