@@ -833,3 +833,19 @@ def test_fuzzed_scenes_bit_exact(oracle, schedule):
         assert np.array_equal(gpu.view(np.uint32), ref.view(np.uint32)), f"fuzz {seed}: {int((gpu.view(np.uint32) != ref.view(np.uint32)).any(axis=-1).sum())} pixels differ"
         _stats_equal(pt.stats(), st, ALL_COUNTERS)
         pt.close()
+
+
+@pytest.mark.parametrize("schedule", [0, 1])
+def test_fuzzed_instanced_scenes_bit_exact(oracle, schedule):
+    """HAS_TLAS: ten instanced scenes with random instance counts (1 ... 60), placements, rotations and non-uniform scales."""
+    for k, (count, seed) in enumerate(((1, 3), (2, 4), (3, 5), (7, 6), (12, 7), (20, 8), (33, 9), (47, 10), (60, 11), (25, 12))):
+        s = scenes.instanced_scene(count=count, detail=6 + k % 3 * 3, seed=seed)
+        pt = PathTracer(s, width=64, height=40, samplesPerPass=2, schedule=schedule)
+        pt.set_stats_level(1)
+        p = pt.params(seed=0x7145 + k)
+        pt.render_pass(p)
+        gpu = pt.readback()
+        ref, st = _oracle_frame(oracle, pt, p, shadow_any_hit=True)
+        assert np.array_equal(gpu.view(np.uint32), ref.view(np.uint32)), f"instanced {count}/{seed}: {int((gpu.view(np.uint32) != ref.view(np.uint32)).any(axis=-1).sum())} pixels differ"
+        _stats_equal(pt.stats(), st, ALL_COUNTERS)
+        pt.close()

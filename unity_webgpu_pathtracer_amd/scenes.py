@@ -782,11 +782,11 @@ def _trs(translate=(0, 0, 0), rotate_y_deg=0.0, rotate_x_deg=0.0, scale=(1, 1, 1
     return T @ Ry @ Rx @ S
 
 
-def instanced_scene(count: int = 14, detail: int = 12) -> Scene:
+def instanced_scene(count: int = 14, detail: int = 12, seed: int = 17) -> Scene:
     """A floor plus `count` instances of three small meshes (sphere, box, cone) with rotations, translations and
     non-uniform scales -- the last on purpose: the reference compares instance-LOCAL hit parameters against the
     world-space distance of the best hit so far (util/tlas.hlsl:47,216-217), and the restatement must keep that."""
-    rng = np.random.RandomState(17)
+    rng = np.random.RandomState(seed)
     meshes = []
     sb = SoupBuilder()
     sb.uv_sphere((0, 0, 0), 0.5, detail * 2, detail, 0)
