@@ -9,11 +9,17 @@
  * Parity pinning: the reference has NO tests, golden vectors or fixtures of its
  * own, and its HLSL cannot be executed in the build container (no dxc/tint/Unity).  The oracle is
  * therefore pinned by (1) byte-exact CWBVH/TLAS data from the reference plugin compiled in place
- * (oracle/_ref), (2) cross-checks of the restated CWBVH traversal against the reference's own
- * tinybvh CPU walkers BVH::Intersect / IsOccluded (oracle/ref_driver.cpp), (3) the RNG known-answer
- * vectors of SURVEY.md Appendix D, (4) analytic checks (white furnace, Lambert under one rectangle
- * light, lobe pdfs integrate to 1).  The SHADING half (brdf/light/material .hlsl) has no executable
- * reference here: for it, parity is "unpinned" beyond (3) and (4) and says so in DESIGN.md.
+ * (oracle/_ref), (2) the restated CWBVH traversal against the reference's OWN walker
+ * BVH8_CWBVH::Intersect, bit for bit in (t, u, v, primitive) (oracle/ref_driver_cwbvh.cpp), and against
+ * BVH::Intersect / IsOccluded (oracle/ref_driver.cpp), (3) the RNG known-answer vectors of SURVEY.md
+ * Appendix D, (4) per-lobe distribution tests of the BSDF (pdf integrates to the usable fraction, sampled
+ * directions follow it) and of SampleEnvMap, (5) closed-form images and one-bounce radiances
+ * (tests/test_oracle_analytic.py: camera, thin lens, light hit, textures, spot / range falloff, sky,
+ * rectangle / point / spot / uniform-sky lighting) and value, pdf and sampled direction of the BSDF
+ * pointwise against a second, float64 transcription, (6) the same frames from a second compiler.
+ * What stays UNPINNED (nothing here can execute HLSL): rounding of the shader's intrinsics, the
+ * evaluation-order rules of DESIGN.md section 3 (the alpha test's unconditional draw among them) and
+ * Unity's texture sampler; DESIGN.md section 7 says so.
  */
 #ifndef PT_ORACLE_H
 #define PT_ORACLE_H
