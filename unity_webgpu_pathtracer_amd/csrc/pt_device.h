@@ -1154,11 +1154,21 @@ PT_DEV v3 sample_brdf(const Material& mat, v3 V, const Onb& onb, v3& L, float& p
 }
 
 // util/random.hlsl:34-41
-PT_DEV v3 random_cosine_hemisphere(v3 normal, uint32_t& rng)
+// GetONB(normal) is ~115 instructions (three normalisations and a division) and the shading step needs it three times: for the
+// face-forward normal (sampling + environment evaluation), and for the NORMAL in RandomCosineHemisphere and in the light's EvalBRDF.
+// On a front-facing hit normal and face-forward normal are the same three floats, hence the same basis: onb_of_normal hands out
+// the basis already computed and only lanes whose hit is back-facing compute their own (a branch the wave skips otherwise).
+PT_DEV Onb onb_of_normal(v3 normal, v3 ffnormal, const Onb& ffOnb)
+{
+    Onb o = ffOnb;
+    if (!(normal.x == ffnormal.x && normal.y == ffnormal.y && normal.z == ffnormal.z)) o = make_onb(normal);
+    return o;
+}
+
+PT_DEV v3 random_cosine_hemisphere(const Onb& onb, uint32_t& rng)     // onb = GetONB(normal)
 {
     float theta = pt_acos(pt_sqrt(rnd(rng)));
     float phi = 2.0f * PT_PI * rnd(rng);
-    Onb onb = make_onb(normal);
     return pt_sin(theta) * (pt_cos(phi) * onb.x + pt_sin(phi) * onb.y + pt_cos(theta) * onb.z);
 }
 
@@ -1291,7 +1301,7 @@ PT_DEV void nee_prepare_environment(const DScene& S, const PTFrameParams& P, v3 
     } else {                                             // :143-157
         Li = mk3(P.EnvironmentColor[0], P.EnvironmentColor[1], P.EnvironmentColor[2]) * P.EnvironmentIntensity;
         lightPdf = 1.0f / (4.0f * PT_PI);
-        lightDir = normalize3(random_cosine_hemisphere(hit.normal, rng));
+        lightDir = normalize3(random_cosine_hemisphere(onb_of_normal(hit.normal, hit.ffnormal, ffOnb), rng));
     }
     out.dir = lightDir;
     out.valid = 1u;
@@ -1309,7 +1319,7 @@ PT_DEV void nee_prepare_environment(const DScene& S, const PTFrameParams& P, v3 
 // analytic-light half of DirectLight (:162-170) + SampleOneLight (:47-58) + EvalLight (:60-114)
 template <bool STATS>
 PT_DEV void nee_prepare_light(const DScene& S, v3 rayDir, const SurfHit& hit, const Material& mat, v3 scatterPos,
-                              uint32_t& rng, NeeRay& out, Counters& cn, const BsdfShared& sh)
+                              uint32_t& rng, NeeRay& out, Counters& cn, const BsdfShared& sh, const Onb& ffOnb)
 {
     out.valid = 0u;
     out.contribution = mk3(0.0f);
@@ -1386,7 +1396,7 @@ PT_DEV void nee_prepare_light(const DScene& S, v3 rayDir, const SurfHit& hit, co
     out.dir = lsDirection;
     out.valid = 1u;
     float pdf = 0.0f;
-    v3 f = eval_brdf(mat, -rayDir, hit.normal, lsDirection, pdf, sh);
+    v3 f = eval_brdf_onb(mat, -rayDir, lsDirection, onb_of_normal(hit.normal, hit.ffnormal, ffOnb), pdf, sh);       // EvalBRDF(..., hit.normal, ...): GetONB(normal)
     float lightPdf = 1.0f;
     if (lsPdf > 0.0f) lightPdf = lsPdf;
     out.contribution = Li * f / lightPdf;
@@ -1534,6 +1544,18 @@ PT_DEV void path_apply_pending(PathRegs& r, bool occEnv, bool occLight)
 // ---- (2) shade the closest hit                           (util/pathtrace.hlsl:27-127).  Precondition: r.state == PS_TRACE.
 // Reads r.ro, rd, radiance, throughput, scatterPdf, maxRoughness, rng, depth; writes those plus state, hasPending, green,
 // env, light, neeOrigin, pendThroughput.
+// -DPT_SHADE_TIME (diagnostics build, STATS instantiations only; tools/experiments/shade_time.py): clock ticks >> 4 a WAVE spends in the
+// sections of the shading step, through the work counters: attrFetches = hit attributes + light intersection, pixelsRead = miss / light-hit
+// branch, materialFetches = material + textures, texelFetches = environment NEE, lightFetches = light NEE, texDescFetches = BSDF sampling + the
+// rest, tlasNodeVisits = the whole step, instanceVisits = wave executions of the step
+#ifdef PT_SHADE_TIME
+#define PT_ST_BEGIN() const unsigned long long _st0 = __builtin_readcyclecounter()
+#define PT_ST_MARK(var) unsigned long long var = __builtin_readcyclecounter()
+#define PT_ST_ADD(field, a, b) do { if (STATS && (int)(threadIdx.x & 63u) == __ffsll((long long)__ballot(true)) - 1) cn.field += (uint32_t)(((b) - (a)) >> 4); } while (0)
+#else
+#define PT_ST_MARK(var) do { } while (0)
+#define PT_ST_ADD(field, a, b) do { } while (0)
+#endif
 template <bool STATS, class NeeSink = NoNeeSink>
 PT_DEV void path_shade_hit(const DScene& S, const PTFrameParams& P, PathRegs& r, const HitRecord& rec, Counters& cn, NeeSink neeSink = NeeSink())
 {
@@ -1546,11 +1568,17 @@ PT_DEV void path_shade_hit(const DScene& S, const PTFrameParams& P, PathRegs& r,
         hit.materialIndex = 0;
         hit.position = mk3(0.0f); hit.normal = mk3(0.0f); hit.ffnormal = mk3(0.0f);
         hit.uv = {0.0f, 0.0f};
+        PT_ST_MARK(st0);
         if (rec.h.t < PT_FAR_PLANE) {
             if (S.hasTlas) fetch_hit_attributes_tlas(S, r.rd, rec, hit);
             else fetch_hit_attributes<STATS>(S, r.ro, r.rd, rec.h, hit, cn);
         }
         intersect_lights<STATS>(S, r.ro, r.rd, hit, cn);
+        PT_ST_MARK(st1);
+        PT_ST_ADD(attrFetches, st0, st1);
+#ifdef PT_SHADE_TIME
+        if (STATS && (int)(threadIdx.x & 63u) == __ffsll((long long)__ballot(true)) - 1) cn.instanceVisits++;
+#endif
 
         if (!(hit.distance < PT_FAR_PLANE)) {
             v4 sky = sample_sky_radiance(S, P, r.rd, r.depth);
@@ -1558,13 +1586,20 @@ PT_DEV void path_shade_hit(const DScene& S, const PTFrameParams& P, PathRegs& r,
             if (r.depth > 0u) misWeight = power_heuristic(r.scatterPdf, sky.w);
             if (misWeight > 0.0f) r.radiance = r.radiance + misWeight * mk3(sky.x, sky.y, sky.z) * r.throughput;
             r.state = PS_ENDING;
+            PT_ST_MARK(st2);
+            PT_ST_ADD(pixelsRead, st1, st2);
         } else if (S.hasLights && hit.isLight) {
             DLight light = load_light(S, (int)hit.triIndex);
+#ifndef PT_SHADE_TIME
             if (STATS) cn.lightFetches++;
+#endif
             r.radiance = r.radiance + light.emission * r.throughput;
             r.state = PS_ENDING;
         } else {
+            PT_ST_MARK(st3);
             Material material = get_material<STATS>(S, hit.materialIndex, r.rd, hit, cn);
+            PT_ST_MARK(st4);
+            PT_ST_ADD(materialFetches, st3, st4);
             r.maxRoughness = pt_max(r.maxRoughness, material.roughness);
             material.roughness = r.maxRoughness;
             r.radiance = r.radiance + material.emission * r.throughput;
@@ -1587,8 +1622,13 @@ PT_DEV void path_shade_hit(const DScene& S, const PTFrameParams& P, PathRegs& r,
                     BsdfShared sh;
                     tint_colors(material, material.eta, sh.F0, sh.Csheen, sh.Cspec0);
                     const Onb ffOnb = make_onb(hit.ffnormal);
+                    PT_ST_MARK(st5);
                     nee_prepare_environment(S, P, r.rd, hit, material, r.rng, r.env, sh, ffOnb);
-                    nee_prepare_light<STATS>(S, r.rd, hit, material, r.neeOrigin, r.rng, r.light, cn, sh);
+                    PT_ST_MARK(st6);
+                    PT_ST_ADD(texelFetches, st5, st6);
+                    nee_prepare_light<STATS>(S, r.rd, hit, material, r.neeOrigin, r.rng, r.light, cn, sh, ffOnb);
+                    PT_ST_MARK(st7);
+                    PT_ST_ADD(lightFetches, st6, st7);
                     r.pendThroughput = r.throughput;
                     r.hasPending = true;
                     neeSink(r);
@@ -1606,6 +1646,8 @@ PT_DEV void path_shade_hit(const DScene& S, const PTFrameParams& P, PathRegs& r,
                         advance = false;
                     }
                     if (advance) r.depth++;
+                    PT_ST_MARK(st8);
+                    PT_ST_ADD(texDescFetches, st7, st8);
                 }
                 if (advance) {
                     r.rd = scatterL;
