@@ -56,6 +56,8 @@ WORKLOADS = {
     "sponza": dict(scene="sponza", kw=dict(tex_size=1024, detail=1.0), desc="Sponza-class atrium (~250k tris, 24 textured Disney materials, 2 rect lights + sky)"),
     "bunny": dict(scene="bunny", kw={}, desc="bunny-class displaced icosphere (69,620 tris) in the Cornell box"),
     "cornell": dict(scene="cornell", kw={}, desc="Cornell box (8 tris, 1 rectangle light)"),
+    # the HAS_TLAS variant (util/tlas.hlsl) -- 200 instances of three small meshes over a 2-wide TLAS
+    "instanced": dict(scene="instanced", kw=dict(count=200, detail=48), desc="HAS_TLAS: 200 instances (924,888 instanced triangles) of three meshes, rotations and non-uniform scales"),
 }
 
 
